@@ -1,0 +1,68 @@
+// device_ctx.h -- per-device state of a committed scene (internal to libmipt).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <string>
+#include <vector>
+#include "scene_host.h"
+
+namespace mipt {
+
+struct HitRec {
+    float t;
+    int32_t prim;
+};
+
+// A growable device allocation reused across calls (no per-call hipMalloc once warm).
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    hipError_t reserve(size_t bytes) {
+        if (bytes <= cap) return hipSuccess;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+        hipError_t e = hipMalloc(&p, bytes);
+        if (e == hipSuccess) cap = bytes;
+        return e;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+    template <class T> T *as() const { return static_cast<T *>(p); }
+};
+
+struct EventPool {
+    std::vector<hipEvent_t> ev;
+    size_t used = 0;
+    hipEvent_t next() {
+        if (used == ev.size()) {
+            hipEvent_t e;
+            (void)hipEventCreate(&e);
+            ev.push_back(e);
+        }
+        return ev[used++];
+    }
+    void reset() { used = 0; }
+    void destroy() {
+        for (hipEvent_t e : ev) (void)hipEventDestroy(e);
+        ev.clear();
+        used = 0;
+    }
+};
+
+struct DeviceCtx {
+    int device = -1;
+    hipStream_t stream = nullptr;
+    void *arena = nullptr;
+    DScene view;
+    int num_cus = 256;
+    // closest-hit work buffers
+    DevBuf ray_o, ray_d, hits, io_a, io_b, io_c, io_d, counters;
+    // wavefront work buffers (see wavefront.hip)
+    DevBuf wf[24];
+    EventPool events;
+};
+
+}  // namespace mipt

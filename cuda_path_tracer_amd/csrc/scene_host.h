@@ -1,0 +1,64 @@
+// scene_host.h -- host-side scene description and packed arena (internal to libmipt).
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+#include "kd_build.h"
+#include "scene_types.h"
+
+namespace mipt {
+
+struct HostMaterial { float kd[3], ks[3]; };
+struct HostLight { float loc[3], power[3]; };
+struct HostPlane { float point[3], normal[3]; int material; };
+struct HostSphere { float center[3]; float radius; int material; };
+struct HostMesh {
+    std::vector<float> pos, nrm;  // n_tris*9 each
+    int material = 0;
+    int64_t n_tris = 0;
+    // filled by commit
+    int64_t tri_base = 0, node_base = 0, ref_base = 0, n_nodes = 0, n_refs = 0;
+    int64_t degenerate_nodes = 0, n_leaves = 0, max_leaf = 0;
+    int max_depth = 0;
+};
+struct HostEnv {
+    int w = 0, h = 0;
+    std::vector<uint32_t> rgbe;  // 6*w*h when loaded from .hdr
+    std::vector<float> f32;      // 6*w*h*3 when given as floats
+    bool present() const { return w > 0; }
+};
+
+// Byte offsets of each section inside the arena (all 256-byte aligned).
+struct ArenaLayout {
+    size_t nodes = 0, boxes = 0, refs = 0, tri_pos = 0, tri_nrm = 0, meshes = 0, spheres = 0, planes = 0, lights = 0,
+           materials = 0, env = 0, total = 0;
+};
+
+struct HostScene {
+    bool cam_set = false;
+    float cam_eye[3], cam_lookat[3], cam_right[3], cam_up[3];
+    std::vector<HostMaterial> materials;
+    std::vector<HostLight> lights;
+    std::vector<HostPlane> planes;
+    std::vector<HostSphere> spheres;
+    std::vector<HostMesh> meshes;
+    HostEnv env;
+
+    bool packed = false;
+    std::vector<uint8_t> arena;  // host copy of the device arena
+    ArenaLayout layout;
+    int64_t total_tris = 0, total_nodes = 0, total_refs = 0;
+    double build_seconds = 0.0;
+
+    // Build kd-trees and pack everything into `arena`.  Returns false and sets err on failure.
+    bool pack(int n_threads, std::string &err);
+    // View whose pointers are `base` + section offsets (base = arena.data() for the host view).
+    DScene view(const void *base) const;
+};
+
+void camera_set(HostScene &s, const float eye[3], const float lookat[3], const float vup[3], float fov);
+bool load_obj(const char *path, const float position[3], const float rotate[3], const float scale[3], HostMesh &out,
+              std::string &err);
+bool load_hdr_rgbe(const char *path, int &w, int &h, std::vector<uint32_t> &texels, std::string &err);
+
+}  // namespace mipt

@@ -1,0 +1,65 @@
+// scene_types.h -- flat SoA scene layout shared by the host packer and the HIP kernels.
+//
+// This layout replaces the reference's pointer-linked device objects (80-byte fat kd nodes with
+// per-leaf 72-byte triangle copies, mesh.cuh:204-220, mesh.cu:35-36) and the ~2 allocations per
+// leaf made through copyToDevice (copyToDevice.h:8-55).  The whole scene lives in ONE device arena:
+//
+//   nodes    uint2[n_nodes]     8-byte kd node.  interior: x = bits(split plane), y = axis<<30 | left child
+//                               (right child = own index + 1); leaf: x = first ref, y = 3<<30 | count
+//   boxes    float4[2*n_nodes]  (minX,maxX,minY,maxY) (minZ,maxZ,-,-): read for the root and on stack pops only
+//   refs     int32[n_refs]      leaf triangle index lists (global triangle ids, leaf order = input order)
+//   tri_pos  float4[3*n_tris]   vertex positions a,b,c (w unused) -- three 16-byte loads per candidate
+//   tri_nrm  float4[3*n_tris]   vertex normals, fetched once for the winning triangle
+//   meshes / spheres / planes / lights / materials: small tables read through scalar loads
+//   env      6 cube faces, raw RGBE (4 B/texel) or fp32 RGB
+#pragma once
+#include <stdint.h>
+#include "pt_math.h"
+
+namespace mipt {
+
+constexpr int kMaxLeafTris = 50;       // constants.cuh:12
+constexpr int kMaxKdHeight = 15;       // constants.cuh:13
+constexpr int kAllowedDiff = 20;       // constants.cuh:14
+constexpr int kSplitSearchDepth = 20;  // constants.cuh:15
+constexpr int kStackDepth = 18;        // >= 16 interior levels + root (reference: int[15], Q9)
+constexpr int kMaxPathDepth = 16;      // accepted cam_depth / light_depth
+
+constexpr uint32_t kLeafTag = 3u << 30;
+constexpr uint32_t kIdxMask = (1u << 30) - 1;
+
+struct KdNode {
+    uint32_t a, b;
+};
+
+struct DMesh {
+    int32_t root;      // global node index of the mesh's root
+    int32_t tri_base;  // first global triangle id
+    int32_t n_tris;
+    int32_t material;
+};
+
+struct f4 {
+    float x, y, z, w;
+};
+
+// Device view of the packed scene; passed to kernels by value (kernarg -> scalar loads).
+struct DScene {
+    const KdNode *nodes;
+    const f4 *boxes;
+    const int32_t *refs;
+    const f4 *tri_pos;
+    const f4 *tri_nrm;
+    const DMesh *meshes;
+    const f4 *spheres;    // 2 per sphere: (center, radius) (mat bits, -, -, -)
+    const f4 *planes;     // 2 per plane:  (point, mat bits) (normal, -)
+    const f4 *lights;     // 2 per light:  (location, -) (power, -)
+    const f4 *materials;  // 2 per material: (diffuse, -) (mirror, -)
+    const uint32_t *env_rgbe;  // 6*w*h texels R|G<<8|B<<16|E<<24, or null
+    const float *env_f32;      // 6*w*h*3 floats, or null
+    int32_t n_meshes, n_spheres, n_planes, n_lights, n_materials, total_tris;
+    int32_t env_w, env_h;
+    float cam_eye[3], cam_lookat[3], cam_right[3], cam_up[3];
+};
+
+}  // namespace mipt

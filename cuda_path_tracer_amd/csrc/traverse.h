@@ -1,0 +1,226 @@
+// traverse.h -- kd-tree closest hit over the packed scene (device code; plain C++ so that a
+// test-side harness can also instantiate it on the host against the host copy of the arena).
+//
+// Semantics are those of Scene::firstIntersect (kernel.cu:145-160), Mesh::intersect
+// (mesh.cuh:253-305), Box::intersect / isVertexInBox (mesh.cuh:131-170), Triangle::intersect
+// (mesh.cuh:36-90), Plane::intersect (plane.cuh:18-30) and Sphere::intersect (sphere.cuh:19-37),
+// reproduced bit for bit in fp32, including the quirks catalogued in SURVEY.md 8.1 (Q3-Q8).
+//
+// What is different is the machine mapping:
+//  * 8-byte nodes.  A child's box differs from its parent's in ONE plane (Box::half, mesh.cu:5-30),
+//    so the current node's six bounds and the ray parameter of each of its six slab planes are
+//    carried in registers; descending costs one 8-byte node read and ONE division (the split
+//    plane) instead of two 80-byte nodes and twelve divisions.  The values are the same fp32
+//    values the reference computes, because they come from the same expressions.
+//  * The per-node 32-byte box is re-read only for the root and after a stack pop.
+//  * The traversal stack lives in LDS (one column per lane, bank-conflict free).
+//  * In a leaf, candidates that cannot win (t <= 0, t >= best, point outside the leaf box) are
+//    rejected before the three edge tests; the vertex normals are never touched here.
+#pragma once
+#include "scene_types.h"
+
+namespace mipt {
+
+struct TravCounters {
+    unsigned int nodes, pops, refs, tris;
+};
+
+PT_HD float as_f32(uint32_t u) {
+    union { uint32_t u; float f; } c;
+    c.u = u;
+    return c.f;
+}
+PT_HD uint32_t as_u32(float f) {
+    union { uint32_t u; float f; } c;
+    c.f = f;
+    return c.u;
+}
+
+// Box::isVertexInBox (mesh.cuh:131-139): min-X has no epsilon, every other bound has +eps slack (Q5)
+PT_HD bool point_in_box(f3 p, float lox, float hix, float loy, float hiy, float loz, float hiz) {
+    return (lox <= p.x) & (p.x <= hix + kEps) & (loy <= p.y + kEps) & (p.y <= hiy + kEps) & (loz <= p.z + kEps) &
+           (p.z <= hiz + kEps);
+}
+
+struct SlabBox {
+    float lo[3], hi[3];    // bounds
+    float tlo[3], thi[3];  // ray parameter of each bounding plane: (plane - o)/d   (mesh.cuh:151-160)
+};
+
+// Box::intersect (mesh.cuh:148-170): smallest t > 0 among the six planes whose point lies in the box, else -1
+PT_HD float slab_hit(const SlabBox &b, f3 o, f3 d) {
+    const float inf = __builtin_inff();
+    float best = inf;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const float t0 = b.tlo[k], t1 = b.thi[k];
+        const f3 p0 = o + d * t0, p1 = o + d * t1;
+        const bool ok0 = (t0 > 0.0f) & point_in_box(p0, b.lo[0], b.hi[0], b.lo[1], b.hi[1], b.lo[2], b.hi[2]);
+        const bool ok1 = (t1 > 0.0f) & point_in_box(p1, b.lo[0], b.hi[0], b.lo[1], b.hi[1], b.lo[2], b.hi[2]);
+        const float c0 = ok0 ? t0 : inf, c1 = ok1 ? t1 : inf;
+        best = (c0 < best) ? c0 : best;
+        best = (c1 < best) ? c1 : best;
+    }
+    return (best < inf) ? best : -1.0f;
+}
+
+PT_HD void load_slab(const DScene &sc, int node, f3 o, f3 d, SlabBox &b) {
+    const f4 b0 = sc.boxes[2 * (size_t)node], b1 = sc.boxes[2 * (size_t)node + 1];
+    b.lo[0] = b0.x; b.hi[0] = b0.y; b.lo[1] = b0.z; b.hi[1] = b0.w; b.lo[2] = b1.x; b.hi[2] = b1.y;
+    b.tlo[0] = (b.lo[0] - o.x) / d.x;
+    b.thi[0] = (b.hi[0] - o.x) / d.x;
+    b.tlo[1] = (b.lo[1] - o.y) / d.y;
+    b.thi[1] = (b.hi[1] - o.y) / d.y;
+    b.tlo[2] = (b.lo[2] - o.z) / d.z;
+    b.thi[2] = (b.hi[2] - o.z) / d.z;
+}
+
+// Triangle::intersect up to the inside test (mesh.cuh:36-90) with the leaf acceptance of
+// Mesh::intersect (mesh.cuh:293-296) folded in.  Returns true and updates best when accepted.
+PT_HD bool leaf_candidate(f3 a, f3 b, f3 c, f3 o, f3 d, const SlabBox &box, float &best) {
+    const f3 ab = b - a, ac = c - a;
+    const f3 N = cross3(ab, ac);
+    const float nd = dot3(N, d);
+    if (fabsf(nd) < kEps) return false;  // Q3
+    const float dd = -dot3(N, a);
+    const float t = -(dot3(N, o) + dd) / nd;
+    if (!(t > 0.0f)) return false;                    // t<0 -> raw negative, t==0 -> fails "hit.t > 0"
+    if (!(best < 0.0f || t < best)) return false;     // cannot replace the current best
+    const f3 P = o + d * t;
+    if (!point_in_box(P, box.lo[0], box.hi[0], box.lo[1], box.hi[1], box.lo[2], box.hi[2])) return false;  // Q8
+    f3 C = cross3(ab, P - a);
+    if (dot3(N, C) < 0.0f) return false;
+    const f3 bc = c - b;
+    C = cross3(bc, P - b);
+    if (dot3(N, C) < 0.0f) return false;
+    const f3 ca = a - c;
+    C = cross3(ca, P - c);
+    if (dot3(N, C) < 0.0f) return false;
+    best = t;
+    return true;
+}
+
+// Mesh::intersect (mesh.cuh:253-305).  Stack: push(sp, v) / pop(sp) on a per-lane column.
+template <class Stack, bool COUNT>
+PT_HD void mesh_closest(const DScene &sc, int root, f3 o, f3 d, Stack &stk, float &best_t, int &best_tri,
+                        TravCounters &ctr) {
+    best_t = -1.0f;
+    best_tri = -1;
+    SlabBox cur;
+    load_slab(sc, root, o, d, cur);
+    if (!(slab_hit(cur, o, d) > 0.0f)) return;  // mesh.cuh:254
+    int node = root;
+    int sp = 0;
+    if (COUNT) { ctr.pops++; ctr.nodes++; }
+    for (;;) {
+        KdNode nd = sc.nodes[node];
+        while ((nd.b >> 30) != 3u) {  // mesh.cuh:265
+            const uint32_t ax = nd.b >> 30;
+            const int left = (int)(nd.b & kIdxMask), right = node + 1;
+            const float s = as_f32(nd.a);
+            const float oa = ax == 0 ? o.x : (ax == 1 ? o.y : o.z);
+            const float da = ax == 0 ? d.x : (ax == 1 ? d.y : d.z);
+            const float ts = (s - oa) / da;
+            SlabBox rb = cur, lb = cur;
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                const bool on = ax == (uint32_t)k;
+                rb.lo[k] = on ? s : cur.lo[k];
+                rb.tlo[k] = on ? ts : cur.tlo[k];
+                lb.hi[k] = on ? s : cur.hi[k];
+                lb.thi[k] = on ? ts : cur.thi[k];
+            }
+            const float rt = slab_hit(rb, o, d);  // mesh.cuh:266-269
+            const float lt = slab_hit(lb, o, d);
+            const bool rf = rt < lt;              // Q7: a miss (-1) sorts first
+            const float small_t = rf ? rt : lt, big_t = rf ? lt : rt;
+            const bool go_right = (small_t > 0.0f) ? rf : !rf;  // mesh.cuh:281
+            if ((small_t > 0.0f) & (big_t > 0.0f)) {            // mesh.cuh:285
+                if (sp < kStackDepth) stk.push(sp, rf ? left : right);
+                sp++;
+            }
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                cur.lo[k] = go_right ? rb.lo[k] : cur.lo[k];
+                cur.tlo[k] = go_right ? rb.tlo[k] : cur.tlo[k];
+                cur.hi[k] = go_right ? cur.hi[k] : lb.hi[k];
+                cur.thi[k] = go_right ? cur.thi[k] : lb.thi[k];
+            }
+            node = go_right ? right : left;
+            nd = sc.nodes[node];
+            if (COUNT) ctr.nodes++;
+        }
+        // leaf (mesh.cuh:290-300)
+        const int first = (int)nd.a, count = (int)(nd.b & kIdxMask);
+        float bt = -1.0f;
+        int bi = -1;
+        if (COUNT) { ctr.refs += count; ctr.tris += count; }
+        for (int i = 0; i < count; i++) {
+            const int tri = sc.refs[first + i];
+            const f4 pa = sc.tri_pos[3 * (size_t)tri], pb = sc.tri_pos[3 * (size_t)tri + 1], pc = sc.tri_pos[3 * (size_t)tri + 2];
+            if (leaf_candidate(mk3(pa.x, pa.y, pa.z), mk3(pb.x, pb.y, pb.z), mk3(pc.x, pc.y, pc.z), o, d, cur, bt)) bi = tri;
+        }
+        if (bt > 0.0f) {
+            best_t = bt;
+            best_tri = bi;
+            return;
+        }
+        if (sp == 0) return;
+        sp--;
+        if (sp >= kStackDepth) return;  // unreachable for trees built by kd_build.cpp (depth <= 16)
+        node = stk.pop(sp);
+        load_slab(sc, node, o, d, cur);
+        if (COUNT) { ctr.pops++; ctr.nodes++; }
+    }
+}
+
+// Plane::intersect (plane.cuh:18-30), t only
+PT_HD float plane_t(f3 point, f3 n, f3 o, f3 d) {
+    const float nv = dot3(n, d);
+    if (fabsf(nv) < kEps) return -1.0f;
+    const float t = dot3(n, point - o) / nv;
+    if (t < kEps) return -1.0f;
+    return t;
+}
+// Sphere::intersect (sphere.cuh:19-37), t only
+PT_HD float sphere_t(f3 center, float radius, f3 o, f3 d) {
+    const f3 dist = o - center;
+    const float a = dot3(d, d);
+    const float b = dot3(dist, d) * 2.0f;
+    const float c = dot3(dist, dist) - radius * radius;
+    const float discr = b * b - 4.0f * a * c;
+    if (discr < 0.0f) return -1.0f;
+    const float sq = sqrtf(discr);
+    const float t1 = (-b + sq) / 2.0f / a;
+    const float t2 = (-b - sq) / 2.0f / a;
+    if (t1 <= 0.0f) return -1.0f;
+    return (t2 > 0.0f) ? t2 : t1;
+}
+
+// Scene::firstIntersect (kernel.cu:145-160): meshes, spheres, planes; strict '<' keeps the earlier object.
+// prim: -1 miss; [0,total_tris) triangle; then spheres; then planes.
+template <class Stack, bool COUNT>
+PT_HD void scene_closest(const DScene &sc, f3 o, f3 d, Stack &stk, float &out_t, int &out_prim, TravCounters &ctr) {
+    float best = -1.0f;
+    int prim = -1;
+    for (int m = 0; m < sc.n_meshes; m++) {
+        float t;
+        int tri;
+        mesh_closest<Stack, COUNT>(sc, sc.meshes[m].root, o, d, stk, t, tri, ctr);
+        if (t > 0.0f && (best < 0.0f || t < best)) { best = t; prim = tri; }
+    }
+    for (int i = 0; i < sc.n_spheres; i++) {
+        const f4 s = sc.spheres[2 * i];
+        const float t = sphere_t(mk3(s.x, s.y, s.z), s.w, o, d);
+        if (t > 0.0f && (best < 0.0f || t < best)) { best = t; prim = sc.total_tris + i; }
+    }
+    for (int i = 0; i < sc.n_planes; i++) {
+        const f4 p = sc.planes[2 * i], n = sc.planes[2 * i + 1];
+        const float t = plane_t(mk3(p.x, p.y, p.z), mk3(n.x, n.y, n.z), o, d);
+        if (t > 0.0f && (best < 0.0f || t < best)) { best = t; prim = sc.total_tris + sc.n_spheres + i; }
+    }
+    out_t = best;
+    out_prim = prim;
+}
+
+}  // namespace mipt

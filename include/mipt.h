@@ -1,0 +1,111 @@
+/*
+ * mipt.h -- C-ABI of the MI355X-native path-tracer core (libmipt.so).
+ *
+ * This is the drop-in boundary for the rendering path of fazakasreka/cuda-path-tracer.
+ * The reference has no FFI; its boundary is the C++ scene-construction surface plus the
+ * `render` kernel launch inside one translation unit.  Every entry point below names the
+ * reference interface it replaces (paths relative to /root/reference/cuda-path-tracer/).
+ *
+ * Conventions: plain pointers and sizes only; 0 (or an id >= 0) = OK, negative = error and
+ * mipt_last_error() (thread-local) describes it; host buffers are owned by the caller,
+ * device memory by the scene; one host thread drives a scene at a time.  All arithmetic on
+ * the path is fp32 in the reference's operation order (no FMA contraction).
+ */
+#ifndef MIPT_H
+#define MIPT_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct mipt_scene mipt_scene;
+
+/* Replaces the compile-time constants of constants/constants.cuh:6-9 and the launch geometry
+ * of kernel.cu:397 with a runtime POD. */
+typedef struct mipt_render_config {
+    int32_t width, height;   /* screenWidth/screenHeight (constants.cuh:6)                        */
+    int32_t spp;             /* nSamples (constants.cuh:9): normalisation constant, kernel.cu:343 */
+    int32_t cam_depth;       /* camera sub-path vertices (maxdepth, constants.cuh:8)              */
+    int32_t light_depth;     /* light sub-path vertices; 0 = "simple" path tracing (README.md:17) */
+    int32_t use_envmap;      /* add cube-map radiance on a camera-ray miss (img/environment_mapping.png) */
+    uint32_t seed;           /* counter-based RNG key (replaces curand_init, kernel.cu:331)       */
+    int32_t sample_begin, sample_end, sample_stride; /* this call renders s = begin, begin+stride, ... < end */
+    int32_t samples_per_pass; /* samples of every pixel in flight per wavefront pass; 0 = auto    */
+} mipt_render_config;
+
+/* Replaces the wall-clock print of kernel.cu:395-412 with per-stage GPU timings and ray counts. */
+typedef struct mipt_stats {
+    int64_t rays_total;      /* closest-hit queries traced (all are closest-hit, kernel.cu:249,268) */
+    int64_t rays_camera, rays_shadow, rays_light;
+    int64_t samples;         /* pixel-samples rendered by this call                              */
+    int64_t extend_launches; /* launches of the kd closest-hit kernel                            */
+    double ms_total;         /* GPU time of the whole call (HIP events on the scene's stream)    */
+    double ms_extend;        /* summed GPU time of the closest-hit kernel launches               */
+    double ms_other;         /* raygen/shade/connect/resolve/accumulate                          */
+    /* traversal counters, filled only when MIPT_FLAG_COUNTERS is requested (slower kernel):   */
+    int64_t ctr_nodes, ctr_pops, ctr_refs, ctr_tris, ctr_hits;
+} mipt_stats;
+
+enum { MIPT_FLAG_COUNTERS = 1 };
+
+/* ---- scene construction: replaces Scene::build (kernel.cu:52-142) --------------------- */
+int  mipt_scene_create(mipt_scene **out);                        /* `Scene scene;` kernel.cu:383 */
+void mipt_scene_destroy(mipt_scene *);                           /* reference never frees (cudaDeviceReset, kernel.cu:425) */
+int  mipt_scene_set_camera(mipt_scene *, const float eye[3], const float lookat[3], const float vup[3],
+                           float fov_rad);                       /* Camera::set camera.cuh:9 */
+int  mipt_scene_add_material(mipt_scene *, const float diffuse[3], const float mirror[3]); /* Material() material.cuh:9; returns id */
+int  mipt_scene_add_light(mipt_scene *, const float location[3], const float power[3]);    /* Light() light.cuh:15 */
+int  mipt_scene_add_plane(mipt_scene *, const float point[3], const float normal[3], int material);  /* Plane() plane.cuh:14 */
+int  mipt_scene_add_sphere(mipt_scene *, const float center[3], float radius, int material);         /* Sphere() sphere.cuh:15 */
+/* De-indexed world-space triangles: pos/nrm are n_tris*9 floats (a,b,c).  Replaces Mesh(std::vector<Triangle*>) mesh.cuh:240 */
+int  mipt_scene_add_mesh(mipt_scene *, const float *pos, const float *nrm, int64_t n_tris, int material);
+/* Replaces MeshObject(objPath, position, rotate, scale, Material*) mesh.cuh:322 -> readObjIntoMesh mesh.cu:232-317
+ * (v / vn / f with p//n or p/t/n, SRT baked in, including the y/z swap of vec4(vec3,w) math.cuh:55). */
+int  mipt_scene_add_mesh_obj(mipt_scene *, const char *path, const float position[3], const float rotate[3],
+                             const float scale[3], int material);
+/* Replaces EnvMap(folder) envMap.cuh:34-49 + HDRLoader::load HDRLoader.cu:29-97 (px,py,pz,nx,ny,nz.hdr).
+ * Faces are kept as raw RGBE (4 B/texel) and decoded in-kernel, bit-exact w.r.t. convertComponent HDRLoader.cu:99-104. */
+int  mipt_scene_set_envmap_rgbe_dir(mipt_scene *, const char *folder);
+int  mipt_scene_set_envmap_f32(mipt_scene *, const float *faces6, int w, int h);  /* six w*h*3 fp32 faces, order px,py,pz,nx,ny,nz */
+/* kd build (Mesh::getKdTree/Node::makeNodeTree mesh.cu:32-155) + flat SoA packing (8-byte nodes,
+ * triangle index lists) + one arena upload per device.  Replaces every copyToDevice call site
+ * (copyToDevice.h:8-55; kernel.cu:61-139, mesh.cu:35-36,176,200, envMap.cuh:27,31, intersectable.cuh:12).
+ * n_devices == 0 packs on the host only (no GPU needed; for inspecting the packed tree). */
+int  mipt_scene_commit(mipt_scene *, const int *device_ids, int n_devices);
+
+/* ---- rendering: replaces render<<<>>> + cudaMemcpy D2H (kernel.cu:310-346,397,416) ---- */
+/* out_rgb_f32: host W*H*3, row r <-> camera Y=r (camera.cuh:18), value = sum_s trace_s / spp. With
+ * several committed devices the sample set is partitioned s mod G and summed on the host. */
+int  mipt_render(mipt_scene *, const mipt_render_config *, float *out_rgb_f32, mipt_stats *out);
+/* Same on committed device slot `dev_slot`, ADDING into a caller-provided DEVICE buffer (W*H*3 fp32),
+ * e.g. the tensor a caller then all-reduces over RCCL. Synchronises the scene stream before returning. */
+int  mipt_render_device(mipt_scene *, int dev_slot, const mipt_render_config *, float *d_accum_rgb, mipt_stats *out);
+
+/* Closest hit for explicit rays: Scene::firstIntersect kernel.cu:145-160 on Ray(o, d) (ray.cuh:10 normalises d).
+ * prim_id: -1 = miss, else triangles in mesh/face order, then spheres, then planes (Hit carries no id, hit.cuh:9-15). */
+int  mipt_trace_closest(mipt_scene *, const float *ray_o, const float *ray_d, int64_t n, int32_t *prim_id, float *t,
+                        mipt_stats *out, int flags);
+/* Same with all four buffers resident on device slot `dev_slot` (n*3, n*3, n, n elements). */
+int  mipt_trace_closest_device(mipt_scene *, int dev_slot, const float *d_ray_o, const float *d_ray_d, int64_t n,
+                               int32_t *d_prim_id, float *d_t, mipt_stats *out, int flags);
+/* EnvMap::getPixelColor envMap.cuh:50-89 evaluated on the device for n directions (host buffers). */
+int  mipt_env_lookup(mipt_scene *, const float *dirs, int64_t n, float *rgb);
+
+/* ---- introspection of the packed scene (host side; valid after commit) ---------------- */
+int  mipt_mesh_count(mipt_scene *);
+int  mipt_kd_sizes(mipt_scene *, int mesh, int64_t *n_nodes, int64_t *n_refs, int64_t *n_tris);
+/* Unpacks the 8-byte nodes of one mesh: boxes n*6 (minX,maxX,minY,maxY,minZ,maxZ), axis, left/right child
+ * (-1 for leaves; indices local to the mesh), first/count of the leaf's reference range, refs (local triangle ids). */
+int  mipt_kd_export(mipt_scene *, int mesh, float *boxes, int32_t *axis, int32_t *left, int32_t *right,
+                    int32_t *first, int32_t *count, int32_t *refs);
+int  mipt_mesh_triangles(mipt_scene *, int mesh, float *pos9, float *nrm9);
+int64_t mipt_scene_device_bytes(mipt_scene *);   /* size of the packed arena */
+double  mipt_scene_build_seconds(mipt_scene *);  /* host kd build + pack time of the last commit */
+
+const char *mipt_last_error(void);   /* replaces fprintf(stderr, ...) and continue (copyToDevice.h:10-17) */
+const char *mipt_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

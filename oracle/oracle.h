@@ -1,0 +1,97 @@
+/*
+ * oracle.h -- C interface of the CPU ORACLE.
+ *
+ * TEST INFRASTRUCTURE ONLY.  This is a from-scratch CPU restatement of the
+ * rendering semantics of fazakasreka/cuda-path-tracer (reference file:line
+ * citations are on every function in oracle.cpp).  Only tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg may load it.  The
+ * product library (cuda_path_tracer_amd/csrc -> libmipt.so) never includes,
+ * links or calls anything in this directory.
+ *
+ * PARITY UNPINNED: the reference ships no tests, golden vectors or fixtures
+ *  and building/running the reference's own sources was
+ * denied by the environment, so this restatement is
+ * pinned only by (a) analytic known-answer tests, (b) its own brute-force
+ * cross-checks and (c) the Philox4x32-10 published test vectors.
+ */
+#ifndef MIPT_ORACLE_H
+#define MIPT_ORACLE_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct orc_scene orc_scene;
+
+/* mirrors mipt_render_config (include/mipt.h) field for field */
+typedef struct orc_render_config {
+    int32_t width, height;
+    int32_t spp;            /* total samples per pixel (normalisation constant, kernel.cu:343) */
+    int32_t cam_depth;      /* camera sub-path vertices (maxdepth, constants.cuh:8) */
+    int32_t light_depth;    /* light sub-path vertices; 0 = "simple" path tracing */
+    int32_t use_envmap;     /* add env radiance on camera-ray miss (build-defined) */
+    uint32_t seed;
+    int32_t sample_begin, sample_end, sample_stride; /* samples s = begin, begin+stride, ... < end */
+    int32_t pixel_stride;   /* oracle only: render every k-th pixel (others left 0); 1 = all */
+} orc_render_config;
+
+typedef struct orc_counters {   /* traversal counters, totals over a call */
+    int64_t rays;
+    int64_t nodes;          /* kd nodes made current (each costs one 8-byte node read) */
+    int64_t pops;           /* stack pops incl. the root (each costs one box re-read)  */
+    int64_t refs;           /* leaf triangle references read                            */
+    int64_t tris;           /* triangle position fetches (= refs in this traversal)     */
+    int64_t hits;           /* rays with a mesh-triangle closest hit                    */
+    int64_t box_tests;      /* Box::intersect evaluations (reference layout cost)       */
+    int64_t stack_overflow; /* rays that would overflow the reference's int[15] (Q9)    */
+    int64_t max_stack;
+} orc_counters;
+
+orc_scene *orc_scene_create(void);
+void orc_scene_destroy(orc_scene *);
+int orc_scene_set_camera(orc_scene *, const float eye[3], const float lookat[3], const float vup[3], float fov_rad);
+int orc_scene_add_material(orc_scene *, const float diffuse[3], const float mirror[3]);
+int orc_scene_add_light(orc_scene *, const float location[3], const float power[3]);
+int orc_scene_add_plane(orc_scene *, const float point[3], const float normal[3], int material);
+int orc_scene_add_sphere(orc_scene *, const float center[3], float radius, int material);
+int orc_scene_add_mesh(orc_scene *, const float *pos, const float *nrm, int64_t n_tris, int material);
+int orc_scene_add_mesh_obj(orc_scene *, const char *path, const float position[3], const float rotate[3],
+                           const float scale[3], int material);
+int orc_scene_set_envmap_rgbe_dir(orc_scene *, const char *folder);
+int orc_scene_set_envmap_f32(orc_scene *, const float *faces6, int w, int h);
+int orc_scene_commit(orc_scene *, int n_threads);
+
+/* closest hit on n rays; dir is normalised the way the reference Ray ctor does.
+ * prim_id: -1 miss, else global id (triangles in mesh order, then spheres, then planes).
+ * brute != 0: test every triangle of every mesh instead of walking the kd-tree.       */
+int orc_trace_closest(orc_scene *, const float *ray_o, const float *ray_d, int64_t n, int32_t *prim_id,
+                      float *t, orc_counters *ctr, int brute, int n_threads);
+int orc_render(orc_scene *, const orc_render_config *, float *out_rgb, orc_counters *ctr, int n_threads);
+
+/* kd-tree export for structural goldens. Arrays may be NULL to query sizes only. */
+int orc_mesh_count(orc_scene *);
+int orc_kd_sizes(orc_scene *, int mesh, int64_t *n_nodes, int64_t *n_refs, int64_t *n_tris);
+int orc_kd_export(orc_scene *, int mesh, float *boxes /*n*6*/, int32_t *axis, int32_t *left, int32_t *right,
+                  int32_t *first, int32_t *count, int32_t *refs);
+int orc_mesh_triangles(orc_scene *, int mesh, float *pos9, float *nrm9);
+
+/* unit-level entry points for known-answer tests */
+void orc_normalize(const float v[3], float out[3]);
+float orc_triangle_intersect(const float pos9[9], const float o[3], const float d_unit[3]);
+float orc_box_intersect(const float box6[6], const float o[3], const float d_unit[3]);
+int orc_box_contains(const float box6[6], const float p[3]);
+float orc_plane_intersect(const float point[3], const float normal_unit[3], const float o[3], const float d_unit[3]);
+float orc_sphere_intersect(const float center[3], float radius, const float o[3], const float d_unit[3]);
+void orc_camera_ray(orc_scene *, float X, float Y, int W, int H, float o[3], float d[3]);
+void orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
+float orc_rng_uniform(uint32_t seed, uint32_t pixel, uint32_t sample, uint32_t draw);
+int orc_env_lookup(orc_scene *, const float *dirs, int64_t n, float *rgb, int32_t *face, int32_t *pos);
+int orc_hdr_load(const char *path, int *w, int *h, float *cols /* may be NULL */);
+void orc_srt_matrix(const float scale[3], const float rotate[3], const float translate[3], float m16[16],
+                    float inv_t16[16]);
+const char *orc_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
