@@ -1,0 +1,271 @@
+"""ctypes binding of the CPU oracle (oracle/liboracle.so).  TEST INFRASTRUCTURE ONLY: imported by tests/,
+__graft_entry__.smoke() and bench.py's cpu_baseline leg, never by the product package."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "liboracle.so")
+
+
+class OrcConfig(C.Structure):
+    _fields_ = [
+        ("width", C.c_int32), ("height", C.c_int32), ("spp", C.c_int32), ("cam_depth", C.c_int32),
+        ("light_depth", C.c_int32), ("use_envmap", C.c_int32), ("seed", C.c_uint32),
+        ("sample_begin", C.c_int32), ("sample_end", C.c_int32), ("sample_stride", C.c_int32),
+        ("pixel_stride", C.c_int32),
+    ]
+
+
+class OrcCounters(C.Structure):
+    _fields_ = [(n, C.c_int64) for n in ("rays", "nodes", "pops", "refs", "tris", "hits", "box_tests",
+                                         "stack_overflow", "max_stack")]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
+_lib = None
+_VP = C.c_void_p
+_F3 = C.POINTER(C.c_float)
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", _HERE])
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        build()
+    lib = C.CDLL(LIB_PATH)
+    lib.orc_scene_create.restype = _VP
+    lib.orc_last_error.restype = C.c_char_p
+    for name in ("orc_triangle_intersect", "orc_box_intersect", "orc_plane_intersect", "orc_sphere_intersect",
+                 "orc_rng_uniform"):
+        getattr(lib, name).restype = C.c_float
+    lib.orc_scene_destroy.argtypes = [_VP]
+    lib.orc_scene_set_camera.argtypes = [_VP, _F3, _F3, _F3, C.c_float]
+    lib.orc_scene_add_material.argtypes = [_VP, _F3, _F3]
+    lib.orc_scene_add_light.argtypes = [_VP, _F3, _F3]
+    lib.orc_scene_add_plane.argtypes = [_VP, _F3, _F3, C.c_int]
+    lib.orc_scene_add_sphere.argtypes = [_VP, _F3, C.c_float, C.c_int]
+    lib.orc_scene_add_mesh.argtypes = [_VP, _VP, _VP, C.c_int64, C.c_int]
+    lib.orc_scene_add_mesh_obj.argtypes = [_VP, C.c_char_p, _F3, _F3, _F3, C.c_int]
+    lib.orc_scene_set_envmap_rgbe_dir.argtypes = [_VP, C.c_char_p]
+    lib.orc_scene_set_envmap_f32.argtypes = [_VP, _VP, C.c_int, C.c_int]
+    lib.orc_scene_commit.argtypes = [_VP, C.c_int]
+    lib.orc_trace_closest.argtypes = [_VP, _VP, _VP, C.c_int64, _VP, _VP, C.POINTER(OrcCounters), C.c_int, C.c_int]
+    lib.orc_render.argtypes = [_VP, C.POINTER(OrcConfig), _VP, C.POINTER(OrcCounters), C.c_int]
+    lib.orc_mesh_count.argtypes = [_VP]
+    lib.orc_kd_sizes.argtypes = [_VP, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+    lib.orc_kd_export.argtypes = [_VP, C.c_int] + [_VP] * 7
+    lib.orc_mesh_triangles.argtypes = [_VP, C.c_int, _VP, _VP]
+    lib.orc_normalize.argtypes = [_F3, _F3]
+    lib.orc_triangle_intersect.argtypes = [_VP, _F3, _F3]
+    lib.orc_box_intersect.argtypes = [_VP, _F3, _F3]
+    lib.orc_box_contains.argtypes = [_VP, _F3]
+    lib.orc_plane_intersect.argtypes = [_F3, _F3, _F3, _F3]
+    lib.orc_sphere_intersect.argtypes = [_F3, C.c_float, _F3, _F3]
+    lib.orc_camera_ray.argtypes = [_VP, C.c_float, C.c_float, C.c_int, C.c_int, _F3, _F3]
+    lib.orc_philox4x32_10.argtypes = [_VP, _VP, _VP]
+    lib.orc_rng_uniform.argtypes = [C.c_uint32] * 4
+    lib.orc_env_lookup.argtypes = [_VP, _VP, C.c_int64, _VP, _VP, _VP]
+    lib.orc_hdr_load.argtypes = [C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int), _VP]
+    lib.orc_srt_matrix.argtypes = [_F3, _F3, _F3, _VP, _VP]
+    _lib = lib
+    return lib
+
+
+def _f3(v):
+    return (C.c_float * 3)(*[float(x) for x in v])
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class OracleError(RuntimeError):
+    pass
+
+
+def _check(rc):
+    if rc < 0:
+        raise OracleError(load().orc_last_error().decode(errors="replace"))
+    return rc
+
+
+class OracleScene:
+    """Same method names as cuda_path_tracer_amd.scene.Scene, evaluated by the CPU restatement."""
+
+    def __init__(self, threads=0):
+        self._lib = load()
+        self._h = C.c_void_p(self._lib.orc_scene_create())
+        self.threads = int(threads)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.orc_scene_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_camera(self, eye, lookat, vup, fov_rad):
+        _check(self._lib.orc_scene_set_camera(self._h, _f3(eye), _f3(lookat), _f3(vup), float(fov_rad)))
+
+    def add_material(self, diffuse, mirror):
+        return _check(self._lib.orc_scene_add_material(self._h, _f3(diffuse), _f3(mirror)))
+
+    def add_light(self, location, power):
+        return _check(self._lib.orc_scene_add_light(self._h, _f3(location), _f3(power)))
+
+    def add_plane(self, point, normal, material):
+        return _check(self._lib.orc_scene_add_plane(self._h, _f3(point), _f3(normal), int(material)))
+
+    def add_sphere(self, center, radius, material):
+        return _check(self._lib.orc_scene_add_sphere(self._h, _f3(center), float(radius), int(material)))
+
+    def add_mesh(self, pos, nrm, material):
+        pos = np.ascontiguousarray(pos, dtype=np.float32).reshape(-1, 9)
+        nrm = np.ascontiguousarray(nrm, dtype=np.float32).reshape(-1, 9)
+        return _check(self._lib.orc_scene_add_mesh(self._h, _ptr(pos), _ptr(nrm), pos.shape[0], int(material)))
+
+    def add_mesh_obj(self, path, position, rotate, scale, material):
+        return _check(self._lib.orc_scene_add_mesh_obj(self._h, str(path).encode(), _f3(position), _f3(rotate),
+                                                       _f3(scale), int(material)))
+
+    def set_envmap_dir(self, folder):
+        folder = str(folder)
+        if not folder.endswith("/"):
+            folder += "/"
+        _check(self._lib.orc_scene_set_envmap_rgbe_dir(self._h, folder.encode()))
+
+    def set_envmap_f32(self, faces6):
+        faces6 = np.ascontiguousarray(faces6, dtype=np.float32)
+        _check(self._lib.orc_scene_set_envmap_f32(self._h, _ptr(faces6), faces6.shape[2], faces6.shape[1]))
+
+    def commit(self, devices=()):
+        _check(self._lib.orc_scene_commit(self._h, self.threads))
+
+    def trace_closest(self, ray_o, ray_d, brute=False, counters=True):
+        ray_o = np.ascontiguousarray(ray_o, dtype=np.float32).reshape(-1, 3)
+        ray_d = np.ascontiguousarray(ray_d, dtype=np.float32).reshape(-1, 3)
+        n = ray_o.shape[0]
+        prim = np.empty(n, np.int32)
+        t = np.empty(n, np.float32)
+        ctr = OrcCounters()
+        _check(self._lib.orc_trace_closest(self._h, _ptr(ray_o), _ptr(ray_d), n, _ptr(prim), _ptr(t), C.byref(ctr),
+                                           int(bool(brute)), self.threads))
+        return prim, t, ctr.as_dict()
+
+    def render(self, cfg, pixel_stride=1):
+        """cfg: any object with the mipt_render_config field names."""
+        oc = OrcConfig(cfg.width, cfg.height, cfg.spp, cfg.cam_depth, cfg.light_depth, cfg.use_envmap, cfg.seed,
+                       cfg.sample_begin, cfg.sample_end, max(1, cfg.sample_stride), int(pixel_stride))
+        img = np.zeros((cfg.height, cfg.width, 3), np.float32)
+        ctr = OrcCounters()
+        _check(self._lib.orc_render(self._h, C.byref(oc), _ptr(img), C.byref(ctr), self.threads))
+        return img, ctr.as_dict()
+
+    def env_lookup(self, dirs, with_index=False):
+        dirs = np.ascontiguousarray(dirs, dtype=np.float32).reshape(-1, 3)
+        rgb = np.empty_like(dirs)
+        face = np.empty(dirs.shape[0], np.int32)
+        pos = np.empty(dirs.shape[0], np.int32)
+        _check(self._lib.orc_env_lookup(self._h, _ptr(dirs), dirs.shape[0], _ptr(rgb), _ptr(face), _ptr(pos)))
+        return (rgb, face, pos) if with_index else rgb
+
+    def mesh_count(self):
+        return self._lib.orc_mesh_count(self._h)
+
+    def kd_export(self, mesh):
+        nn, nr, nt = C.c_int64(), C.c_int64(), C.c_int64()
+        _check(self._lib.orc_kd_sizes(self._h, int(mesh), C.byref(nn), C.byref(nr), C.byref(nt)))
+        out = {
+            "boxes": np.empty((nn.value, 6), np.float32), "axis": np.empty(nn.value, np.int32),
+            "left": np.empty(nn.value, np.int32), "right": np.empty(nn.value, np.int32),
+            "first": np.empty(nn.value, np.int32), "count": np.empty(nn.value, np.int32),
+            "refs": np.empty(nr.value, np.int32),
+        }
+        _check(self._lib.orc_kd_export(self._h, int(mesh), *[_ptr(out[k]) for k in
+                                                             ("boxes", "axis", "left", "right", "first", "count", "refs")]))
+        out["n_tris"] = nt.value
+        return out
+
+    def mesh_triangles(self, mesh):
+        nt = C.c_int64()
+        _check(self._lib.orc_kd_sizes(self._h, int(mesh), None, None, C.byref(nt)))
+        pos = np.empty((nt.value, 3, 3), np.float32)
+        nrm = np.empty((nt.value, 3, 3), np.float32)
+        _check(self._lib.orc_mesh_triangles(self._h, int(mesh), _ptr(pos), _ptr(nrm)))
+        return pos, nrm
+
+    def camera_ray(self, X, Y, W, H):
+        o, d = (C.c_float * 3)(), (C.c_float * 3)()
+        self._lib.orc_camera_ray(self._h, float(X), float(Y), int(W), int(H), o, d)
+        return np.array(o[:], np.float32), np.array(d[:], np.float32)
+
+
+# ---- unit-level helpers for known-answer tests ------------------------------------------------
+def normalize(v):
+    out = (C.c_float * 3)()
+    load().orc_normalize(_f3(v), out)
+    return np.array(out[:], np.float32)
+
+
+def triangle_intersect(pos9, o, d):
+    p = np.ascontiguousarray(pos9, np.float32).reshape(9)
+    return float(load().orc_triangle_intersect(_ptr(p), _f3(o), _f3(d)))
+
+
+def box_intersect(box6, o, d):
+    b = np.ascontiguousarray(box6, np.float32).reshape(6)
+    return float(load().orc_box_intersect(_ptr(b), _f3(o), _f3(d)))
+
+
+def box_contains(box6, p):
+    b = np.ascontiguousarray(box6, np.float32).reshape(6)
+    return bool(load().orc_box_contains(_ptr(b), _f3(p)))
+
+
+def plane_intersect(point, normal, o, d):
+    return float(load().orc_plane_intersect(_f3(point), _f3(normal), _f3(o), _f3(d)))
+
+
+def sphere_intersect(center, radius, o, d):
+    return float(load().orc_sphere_intersect(_f3(center), float(radius), _f3(o), _f3(d)))
+
+
+def philox4x32_10(ctr, key):
+    c = np.array(ctr, np.uint32)
+    k = np.array(key, np.uint32)
+    out = np.zeros(4, np.uint32)
+    load().orc_philox4x32_10(_ptr(c), _ptr(k), _ptr(out))
+    return out
+
+
+def rng_uniform(seed, pixel, sample, draw):
+    return float(load().orc_rng_uniform(int(seed), int(pixel), int(sample), int(draw)))
+
+
+def hdr_load(path):
+    w, h = C.c_int(), C.c_int()
+    _check(load().orc_hdr_load(str(path).encode(), C.byref(w), C.byref(h), None))
+    cols = np.empty((h.value, w.value, 3), np.float32)
+    _check(load().orc_hdr_load(str(path).encode(), C.byref(w), C.byref(h), _ptr(cols)))
+    return cols
+
+
+def srt_matrix(scale, rotate, translate):
+    m = np.zeros((4, 4), np.float32)
+    it = np.zeros((4, 4), np.float32)
+    load().orc_srt_matrix(_f3(scale), _f3(rotate), _f3(translate), _ptr(m), _ptr(it))
+    return m, it
