@@ -64,7 +64,7 @@ __global__ __launch_bounds__(kExtendBlock) void k_extend(DScene sc, const f4 *__
 }
 
 // Ray(o, d) constructor (ray.cuh:10): dir = d * (1/(|d|+eps)).  Packed xyz triples -> float4 pairs.
-__global__ __launch_bounds__(256) void k_make_rays(const float *__restrict__ o3, const float *__restrict__ d3, int64_t n,
+static __global__ __launch_bounds__(256) void k_make_rays(const float *__restrict__ o3, const float *__restrict__ d3, int64_t n,
                                                    f4 *__restrict__ ray_o, f4 *__restrict__ ray_d) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
@@ -74,7 +74,7 @@ __global__ __launch_bounds__(256) void k_make_rays(const float *__restrict__ o3,
     ray_d[i] = f4{d.x, d.y, d.z, 0.f};
 }
 
-__global__ __launch_bounds__(256) void k_split_hits(const HitRec *__restrict__ hits, int64_t n, int32_t *__restrict__ prim,
+static __global__ __launch_bounds__(256) void k_split_hits(const HitRec *__restrict__ hits, int64_t n, int32_t *__restrict__ prim,
                                                     float *__restrict__ t) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;

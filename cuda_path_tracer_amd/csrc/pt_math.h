@@ -34,4 +34,44 @@ PT_HD float len3(f3 a) { return sqrtf(a.x * a.x + a.y * a.y + a.z * a.z); }
 PT_HD f3 norm3(f3 a) { return a * (1 / (len3(a) + kEps)); }
 PT_HD float avg3(f3 a) { return (a.x + a.y + a.z) / 3.0f; }
 
+// sinf/cosf of Light::randomSampleRay (light.cuh:35-38) for arguments in [0, 2*pi].  Every libm (CUDA's,
+// glibc's, ROCm's) rounds these differently in the last ulp; the build fixes ONE evaluation (Cody-Waite
+// reduction by pi/4 + the classic single-precision minimax polynomials, <= 1-2 ulp) in plain fp32 ops so
+// that the device and any host checker agree bit for bit.
+PT_HD void sincos_reduce(float x, int &j, float &r) {
+    j = (int)(x * 1.27323954473516f);  // 4/pi
+    if (j & 1) j += 1;
+    const float y = (float)j;
+    r = ((x - y * 0.78515625f) - y * 2.4187564849853515625e-4f) - y * 3.77489497744594108e-8f;
+}
+PT_HD float sin_poly(float r) {
+    const float z = r * r;
+    return ((-1.9515295891e-4f * z + 8.3321608736e-3f) * z - 1.6666654611e-1f) * z * r + r;
+}
+PT_HD float cos_poly(float r) {
+    const float z = r * r;
+    return ((2.443315711809948e-5f * z - 1.388731625493765e-3f) * z + 4.166664568298827e-2f) * z * z - 0.5f * z + 1.0f;
+}
+PT_HD float det_sinf(float x) {
+    int j;
+    float r;
+    sincos_reduce(x, j, r);
+    j &= 7;
+    float sign = 1.0f;
+    if (j > 3) { sign = -1.0f; j -= 4; }
+    const float y = (j == 1 || j == 2) ? cos_poly(r) : sin_poly(r);
+    return sign * y;
+}
+PT_HD float det_cosf(float x) {
+    int j;
+    float r;
+    sincos_reduce(x, j, r);
+    j &= 7;
+    float sign = 1.0f;
+    if (j > 3) { sign = -1.0f; j -= 4; }
+    if (j > 1) sign = -sign;
+    const float y = (j == 1 || j == 2) ? sin_poly(r) : cos_poly(r);
+    return sign * y;
+}
+
 }  // namespace mipt

@@ -1,11 +1,515 @@
+// wavefront.hip -- wave64 wavefront path tracer: replaces the per-pixel megakernel `render`
+// (kernel.cu:310-346) and the recursive-by-loop `Scene::trace` (kernel.cu:173-306).
+//
+// One path = one (pixel, sample).  A pass keeps P = pixels x samples_per_pass paths in flight in SoA
+// buffers and advances them one vertex at a time through short kernels:
+//
+//   raygen                    jittered Camera::getRay, RNG draws 0,1                     kernel.cu:338-341
+//   [bidirectional only]
+//   lightgen                  light choice + emission direction                          kernel.cu:178-183
+//   extend / light_shade(i)   light sub-path vertex i, Russian roulette, bounce ray      kernel.cu:184-231
+//   [camera sub-path, per vertex i]
+//   extend                    closest hit of the camera rays                             kernel.cu:240
+//   shade(i)                  direct-light + light-vertex connections emitted as batched shadow rays,
+//                             BSDF sampling / roulette, next ray, queue compaction        kernel.cu:244-302
+//   extend                    closest hit of the shadow-ray batch (all rays are closest-hit, Q10)
+//   resolve                   visibility compare + in-order accumulation of contributions kernel.cu:249-256,268-279
+//   accumulate                image[id] += trace/nSamples, in sample order               kernel.cu:339-343
+//
+// Queues between stages are built with ballot + mbcnt prefix ranks and ONE atomic per wave; ray counts
+// stay on the device (every extend reads its count from memory), so a pass issues no host sync.
+// Every path's contributions are summed by one lane in the reference's order, so for the simple
+// integrator the image is bit-identical to the CPU oracle's.
 #include "wavefront.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstring>
+
+#include "kernels_extend.h"
+#include "shade.h"
+
 namespace mipt {
-int wavefront_render(const HostScene &, DeviceCtx &, const mipt_render_config &, float *, mipt_stats *, std::string &err) {
-    err = "render not implemented yet";
-    return -9;
+namespace {
+
+constexpr int kBlock = 256;
+
+// ---- queue append: ballot + mbcnt rank + one atomic per wave --------------------------------------
+__device__ __forceinline__ int wave_append(bool pred, int *counter) {
+    const unsigned long long mask = __ballot(pred);
+    if (mask == 0ull) return -1;
+    const int n = __popcll(mask);
+    const int leader = __ffsll((long long)mask) - 1;
+    const int lane = (int)(threadIdx.x & 63u);
+    int base = 0;
+    if (lane == leader) base = atomicAdd(counter, n);
+    base = __shfl(base, leader, 64);
+    const int rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned int)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)mask, 0u));
+    return pred ? base + rank : -1;
 }
-int wavefront_env_lookup(DeviceCtx &, const float *, int64_t, float *, std::string &err) {
-    err = "env lookup not implemented yet";
-    return -9;
+
+struct PassParams {
+    int W, H, npix;
+    int spp;             // normalisation constant
+    int sample0;         // sample index of slot 0 of this pass
+    int sample_stride;   // sample index step between slots
+    int n_slots;         // valid slots in this pass (paths = n_slots * npix)
+    int Dc, Dl, K;       // camera depth, light depth, shadow slots per path (1 + Dl)
+    int use_env;
+    uint32_t seed;
+};
+
+struct WfBuffers {
+    f4 *path_o, *path_d, *path_T, *path_rad;
+    HitRec *path_hit;
+    uint32_t *path_rng, *sh_mask;
+    f4 *sh_o, *sh_d, *sh_target, *sh_contrib;
+    HitRec *sh_hit;
+    int *q_cam[2], *q_light[2], *q_shadow;
+    int *counts;                 // per-stage queue counts of the current pass
+    unsigned long long *totals;  // [0] camera rays [1] shadow rays [2] light rays
+    f4 *lv_pos, *lv_nrm, *lv_T;  // light vertices [path*Dl + j]: (pos, valid) (normal, pdf) (throughput, -)
+    f4 *l_o, *l_d, *l_state;     // light rays; l_state = (emission dir, pdf carried to the next vertex)
+    HitRec *l_hit;
+};
+
+// count slots inside `counts`
+constexpr int kCntCam = 0;      // + i  (camera queue feeding vertex i), i <= 16
+constexpr int kCntShadow = 20;  // + i
+constexpr int kCntLight = 40;   // + i
+constexpr int kCntTotal = 64;
+
+__global__ __launch_bounds__(kBlock) void k_raygen(DScene sc, PassParams pp, WfBuffers b) {
+    const int pid = blockIdx.x * kBlock + threadIdx.x;
+    const int n = pp.n_slots * pp.npix;
+    if (pid == 0) {
+        if (pp.Dl == 0) b.counts[kCntCam + 0] = n;
+        else b.counts[kCntLight + 0] = n;
+    }
+    if (pid >= n) return;
+    const int slot = pid / pp.npix, pixel = pid - slot * pp.npix;
+    const int sample = pp.sample0 + slot * pp.sample_stride;
+    const int row = pixel / pp.W, col = pixel - row * pp.W;
+    Rng rng;
+    rng.init(pp.seed, (uint32_t)pixel, (uint32_t)sample, 0u);
+    const float jx = rng.u();  // Q18: first draw -> X, second -> Y
+    const float jy = rng.u();
+    const f3 dir = norm3(camera_dir(sc, (float)col + jx, (float)row + jy, pp.W, pp.H));
+    b.path_o[pid] = mk4(ld3(sc.cam_eye), 0.f);
+    b.path_d[pid] = mk4(dir, 0.f);
+    b.path_T[pid] = f4{1.f, 1.f, 1.f, 1.f};
+    b.path_rad[pid] = f4{0.f, 0.f, 0.f, 0.f};
+    b.path_rng[pid] = rng.draw;
+    b.sh_mask[pid] = 0u;
+    if (pp.Dl == 0) b.q_cam[0][pid] = pid;
+    else b.q_light[0][pid] = pid;
 }
+
+__global__ __launch_bounds__(kBlock) void k_lightgen(DScene sc, PassParams pp, WfBuffers b) {
+    const int pid = blockIdx.x * kBlock + threadIdx.x;
+    const int n = pp.n_slots * pp.npix;
+    if (pid >= n) return;
+    const int slot = pid / pp.npix, pixel = pid - slot * pp.npix;
+    Rng rng;
+    rng.init(pp.seed, (uint32_t)pixel, (uint32_t)(pp.sample0 + slot * pp.sample_stride), b.path_rng[pid]);
+    int li = (int)(rng.u() * ((float)sc.n_lights));  // kernel.cu:178
+    if (li >= sc.n_lights) li = sc.n_lights - 1;      // Q17 clamp
+    const f3 ldir = light_sample_dir(rng);
+    b.l_o[pid] = mk4(xyz(sc.lights[2 * li]), 0.f);
+    b.l_d[pid] = mk4(norm3(ldir), 0.f);               // Ray ctor normalises again (ray.cuh:10)
+    b.l_state[pid] = mk4(ldir, as_f32((uint32_t)li));
+    b.path_rng[pid] = rng.draw;
+    for (int j = 0; j < pp.Dl; j++) {
+        b.lv_pos[(size_t)pid * pp.Dl + j] = f4{0.f, 0.f, 0.f, -1.f};
+        b.lv_T[(size_t)pid * pp.Dl + j] = f4{0.f, 0.f, 0.f, 0.f};
+    }
+}
+
+// light sub-path vertex i (kernel.cu:184-231)
+__global__ __launch_bounds__(kBlock) void k_light_shade(DScene sc, PassParams pp, WfBuffers b, int i) {
+    const int n = b.counts[kCntLight + i];
+    const int *qin = b.q_light[i & 1];
+    int *qout = b.q_light[(i + 1) & 1];
+    for (int base = blockIdx.x * kBlock; base < n; base += gridDim.x * kBlock) {
+        const int idx = base + threadIdx.x;
+        bool cont = false, to_cam = false;
+        int pid = -1;
+        if (idx < n) {
+            pid = qin[idx];
+            const HitRec h = b.l_hit[pid];
+            if (h.prim >= 0) {
+                const f3 o = xyz(b.l_o[pid]), d = xyz(b.l_d[pid]);
+                const Surface s = surface_at(sc, o, d, h.t, h.prim);
+                const f4 st = b.l_state[pid];
+                const size_t vi = (size_t)pid * pp.Dl + i;
+                f3 T = mk3(0.f, 0.f, 0.f);
+                float pdf;
+                if (i == 0) {
+                    const int li = (int)as_u32(st.w);
+                    T = radiance_at(sc, li, s.pos);
+                    pdf = (1.0f / (float)sc.n_lights) * (1.0f / (4.0f * kPi));
+                    to_cam = true;  // Q11: the camera path is traced only if the first light ray hit something
+                } else {
+                    pdf = st.w;  // light_pdf[i] = light_pdf[i-1] * pdf_brdf, carried from vertex i-1
+                }
+                if (i < pp.Dl - 1) {
+                    const int slot = pid / pp.npix, pixel = pid - slot * pp.npix;
+                    Rng rng;
+                    rng.init(pp.seed, (uint32_t)pixel, (uint32_t)(pp.sample0 + slot * pp.sample_stride), b.path_rng[pid]);
+                    const float pd = avg3(s.kd), pm = avg3(s.ks);
+                    const float rnd = rng.u();
+                    if (!(rnd >= pd + pm)) {
+                        const f3 in = (i == 0) ? xyz(st) : norm3(s.pos - xyz(b.lv_pos[vi - 1]));
+                        const f3 Tprev = (i == 0) ? T : xyz(b.lv_T[vi - 1]);
+                        f3 od;
+                        float pdf_b;
+                        bool ok;
+                        if (rnd < pd) {
+                            pdf_b = sample_diffuse(s.nrm, od, rng) * pd;
+                            const float ct = dot3(s.nrm, neg3(in));
+                            ok = !(ct < kEps);
+                            if (ok) T = Tprev * s.kd / kPi * ct;
+                        } else {
+                            pdf_b = sample_mirror(s.nrm, in, od) * pm;
+                            const float ct = dot3(s.nrm, neg3(in));
+                            ok = !(ct < kEps);
+                            if (ok) T = Tprev * s.ks;
+                        }
+                        if (ok) {
+                            b.l_o[pid] = mk4(s.pos + s.nrm * kEps, 0.f);
+                            b.l_d[pid] = mk4(norm3(od), 0.f);
+                            b.l_state[pid] = mk4(xyz(st), pdf * pdf_b);
+                            cont = true;
+                        }
+                    }
+                    b.path_rng[pid] = rng.draw;
+                }
+                b.lv_pos[vi] = mk4(s.pos, 1.0f);
+                b.lv_nrm[vi] = mk4(s.nrm, pdf);
+                b.lv_T[vi] = mk4(T, 0.f);
+            }
+        }
+        const int qi = wave_append(cont, &b.counts[kCntLight + i + 1]);
+        if (cont) qout[qi] = pid;
+        if (i == 0) {
+            const int ci = wave_append(to_cam, &b.counts[kCntCam + 0]);
+            if (to_cam) b.q_cam[0][ci] = pid;
+        }
+    }
+}
+
+// camera sub-path vertex i (kernel.cu:239-303)
+__global__ __launch_bounds__(kBlock) void k_shade(DScene sc, PassParams pp, WfBuffers b, int i) {
+    const int n = b.counts[kCntCam + i];
+    const int *qin = b.q_cam[i & 1];
+    int *qout = b.q_cam[(i + 1) & 1];
+    for (int base = blockIdx.x * kBlock; base < n; base += gridDim.x * kBlock) {
+        const int idx = base + threadIdx.x;
+        bool cont = false;
+        int pid = -1;
+        uint32_t mask = 0u;
+        if (idx < n) {
+            pid = qin[idx];
+            const HitRec h = b.path_hit[pid];
+            const f3 o = xyz(b.path_o[pid]), d = xyz(b.path_d[pid]);
+            const f4 Tp = b.path_T[pid];
+            f3 Tc = xyz(Tp);
+            float pc = Tp.w;
+            if (h.prim < 0) {
+                if (pp.use_env) {  // build-defined extension: radiance of the cube map on a miss
+                    f4 r = b.path_rad[pid];
+                    const f3 add = (Tc / pc) * env_lookup(sc, d);
+                    r.x = r.x + add.x; r.y = r.y + add.y; r.z = r.z + add.z;
+                    b.path_rad[pid] = r;
+                }
+            } else {
+                const Surface s = surface_at(sc, o, d, h.t, h.prim);
+                const size_t sbase = (size_t)pid * pp.K;
+                {  // direct connection to lights[0] (Q13); the shadow ray starts AT the light (Q10)
+                    const f3 lp = xyz(sc.lights[0]);
+                    const f3 ld = norm3(s.pos - lp);
+                    const float ct = dot3(s.nrm, neg3(ld));
+                    if (ct > kEps) {
+                        const f3 lr = radiance_at(sc, 0, s.pos);
+                        const f3 brdf = s.kd / kPi;
+                        const f3 contrib = (Tc / pc) * (lr * brdf * ct);
+                        b.sh_o[sbase] = mk4(lp, 0.f);
+                        b.sh_d[sbase] = mk4(norm3(ld), 0.f);
+                        b.sh_target[sbase] = mk4(s.pos, 0.f);
+                        b.sh_contrib[sbase] = mk4(contrib, 0.f);
+                        mask |= 1u;
+                    }
+                }
+                for (int j = 0; j < pp.Dl; j++) {  // connections to the stored light vertices (Q15, no MIS)
+                    const size_t vi = (size_t)pid * pp.Dl + j;
+                    const f4 lp4 = b.lv_pos[vi];
+                    if (lp4.w < 0.0f) break;
+                    const f3 LT = xyz(b.lv_T[vi]);
+                    if (LT.x == 0.0f && LT.y == 0.0f && LT.z == 0.0f) continue;  // Q14: contributes exactly 0
+                    const f4 ln4 = b.lv_nrm[vi];
+                    const f3 dir = norm3(xyz(lp4) - s.pos);
+                    const float dist = len3(xyz(lp4) - s.pos);
+                    const float cc = dot3(s.nrm, dir), cl = dot3(xyz(ln4), neg3(dir));
+                    if (cc < kEps || cl < kEps) continue;
+                    const float G = cc * cl / (dist * dist);
+                    const f3 brdf = s.kd / kPi;
+                    const f3 cw = Tc * brdf * cc / pc;
+                    const f3 lw = LT / ln4.w;
+                    const f3 contrib = lw * G * cw;
+                    const size_t si = sbase + 1 + j;
+                    b.sh_o[si] = mk4(s.pos + s.nrm * kEps, 0.f);
+                    b.sh_d[si] = mk4(norm3(dir), 0.f);
+                    b.sh_target[si] = mk4(xyz(lp4), 1.f);
+                    b.sh_contrib[si] = mk4(contrib, 0.f);
+                    mask |= 1u << (1 + j);
+                }
+                if (i + 1 < pp.Dc) {  // next vertex (Q16); nothing downstream reads it after the last vertex
+                    const int slot = pid / pp.npix, pixel = pid - slot * pp.npix;
+                    Rng rng;
+                    rng.init(pp.seed, (uint32_t)pixel, (uint32_t)(pp.sample0 + slot * pp.sample_stride), b.path_rng[pid]);
+                    const float pd = avg3(s.kd), pm = avg3(s.ks);
+                    const float rnd = rng.u();
+                    f3 od;
+                    if (rnd < pd) {
+                        const float pdf = sample_diffuse(s.nrm, od, rng);
+                        const float ct = dot3(s.nrm, od);
+                        if (!(ct < kEps)) {
+                            Tc = Tc * s.kd / kPi * ct;
+                            pc = pc * pdf * pd;
+                            cont = true;
+                        }
+                    } else if (rnd < pd + pm) {
+                        const float pdf = sample_mirror(s.nrm, d, od);
+                        Tc = Tc * s.ks;
+                        pc = pc * pdf * pm;
+                        cont = true;
+                    }
+                    b.path_rng[pid] = rng.draw;
+                    if (cont) {
+                        b.path_o[pid] = mk4(s.pos + s.nrm * kEps, 0.f);
+                        b.path_d[pid] = mk4(norm3(od), 0.f);
+                        b.path_T[pid] = mk4(Tc, pc);
+                    }
+                }
+            }
+            b.sh_mask[pid] = mask;
+        }
+        const int qi = wave_append(cont, &b.counts[kCntCam + i + 1]);
+        if (cont) qout[qi] = pid;
+        for (int k = 0; k < pp.K; k++) {  // batched shadow rays: one append per slot kind keeps waves converged
+            const bool emit = (mask >> k) & 1u;
+            const int si = wave_append(emit, &b.counts[kCntShadow + i]);
+            if (emit) b.q_shadow[si] = pid * pp.K + k;
+        }
+    }
+}
+
+// visibility + accumulation for vertex i (kernel.cu:249-256, 268-279)
+__global__ __launch_bounds__(kBlock) void k_resolve(PassParams pp, WfBuffers b, int i) {
+    const int n = b.counts[kCntCam + i];
+    const int *qin = b.q_cam[i & 1];
+    for (int idx = blockIdx.x * kBlock + threadIdx.x; idx < n; idx += gridDim.x * kBlock) {
+        const int pid = qin[idx];
+        const uint32_t mask = b.sh_mask[pid];
+        if (mask == 0u) continue;
+        f4 r = b.path_rad[pid];
+        for (int k = 0; k < pp.K; k++) {
+            if (!((mask >> k) & 1u)) continue;
+            const size_t si = (size_t)pid * pp.K + k;
+            const HitRec h = b.sh_hit[si];
+            const f4 tg = b.sh_target[si];
+            const f3 P = xyz(b.sh_o[si]) + xyz(b.sh_d[si]) * h.t;
+            const float dist = len3(P - xyz(tg));
+            bool vis;
+            if (tg.w == 0.0f) vis = (h.t > 0.0f) && (dist < kEps);   // kernel.cu:249
+            else vis = !((h.t < 0.0f) || (dist > kEps));              // kernel.cu:268
+            if (vis) {
+                const f4 c = b.sh_contrib[si];
+                r.x = r.x + c.x; r.y = r.y + c.y; r.z = r.z + c.z;
+            }
+        }
+        b.path_rad[pid] = r;
+    }
+}
+
+// image[id] += trace / nSamples, samples in increasing order (kernel.cu:339-343)
+__global__ __launch_bounds__(kBlock) void k_accumulate(PassParams pp, WfBuffers b, float *accum) {
+    const int pixel = blockIdx.x * kBlock + threadIdx.x;
+    if (pixel >= pp.npix) return;
+    float ax = accum[3 * (size_t)pixel], ay = accum[3 * (size_t)pixel + 1], az = accum[3 * (size_t)pixel + 2];
+    const float ns = (float)pp.spp;
+    for (int s = 0; s < pp.n_slots; s++) {
+        const f4 r = b.path_rad[(size_t)s * pp.npix + pixel];
+        ax = ax + r.x / ns;
+        ay = ay + r.y / ns;
+        az = az + r.z / ns;
+    }
+    accum[3 * (size_t)pixel] = ax;
+    accum[3 * (size_t)pixel + 1] = ay;
+    accum[3 * (size_t)pixel + 2] = az;
+}
+
+__global__ void k_tally(WfBuffers b, int Dc, int Dl) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    unsigned long long cam = 0, sh = 0, li = 0;
+    for (int i = 0; i < Dc; i++) { cam += (unsigned long long)b.counts[kCntCam + i]; sh += (unsigned long long)b.counts[kCntShadow + i]; }
+    for (int i = 0; i < Dl; i++) li += (unsigned long long)b.counts[kCntLight + i];
+    b.totals[0] += cam;
+    b.totals[1] += sh;
+    b.totals[2] += li;
+}
+
+__global__ __launch_bounds__(kBlock) void k_env_lookup(DScene sc, const float *dirs, int64_t n, float *rgb) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const f3 c = env_lookup(sc, mk3(dirs[3 * i], dirs[3 * i + 1], dirs[3 * i + 2]));
+    rgb[3 * i] = c.x; rgb[3 * i + 1] = c.y; rgb[3 * i + 2] = c.z;
+}
+
+#define WF_TRY(expr)                                                              \
+    do {                                                                          \
+        hipError_t e_ = (expr);                                                   \
+        if (e_ != hipSuccess) {                                                   \
+            err = std::string(#expr) + ": " + hipGetErrorString(e_);              \
+            return -2;                                                            \
+        }                                                                         \
+    } while (0)
+
+}  // namespace
+
+int wavefront_env_lookup(DeviceCtx &dc, const float *d_dirs, int64_t n, float *d_rgb, std::string &err) {
+    hipLaunchKernelGGL(k_env_lookup, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, dc.stream, dc.view, d_dirs,
+                       n, d_rgb);
+    WF_TRY(hipGetLastError());
+    WF_TRY(hipStreamSynchronize(dc.stream));
+    return 0;
+}
+
+int wavefront_render(const HostScene &hs, DeviceCtx &dc, const mipt_render_config &cfg, float *d_accum, mipt_stats *st,
+                     std::string &err) {
+    if (st) memset(st, 0, sizeof(*st));
+    if (!hs.cam_set) { err = "camera not set"; return -1; }
+    if (hs.lights.empty()) { err = "at least one light is required (kernel.cu:244)"; return -1; }
+    if (cfg.width <= 0 || cfg.height <= 0 || (int64_t)cfg.width * cfg.height > (1 << 26)) { err = "bad image size"; return -1; }
+    if (cfg.spp <= 0) { err = "spp must be positive"; return -1; }
+    if (cfg.cam_depth < 0 || cfg.cam_depth > kMaxPathDepth || cfg.light_depth < 0 || cfg.light_depth > kMaxPathDepth) {
+        err = "path depth out of range (0..16)";
+        return -1;
+    }
+    if (cfg.use_envmap && !hs.env.present()) { err = "use_envmap set but the scene has no environment map"; return -1; }
+    const int stride = cfg.sample_stride > 0 ? cfg.sample_stride : 1;
+    int64_t n_samples = 0;
+    if (cfg.sample_end > cfg.sample_begin) n_samples = ((int64_t)cfg.sample_end - cfg.sample_begin + stride - 1) / stride;
+    const int npix = cfg.width * cfg.height;
+    const int Dc = cfg.cam_depth, Dl = cfg.light_depth, K = 1 + Dl;
+    WF_TRY(hipSetDevice(dc.device));
+    if (n_samples == 0 || Dc == 0) return 0;
+    int S = cfg.samples_per_pass;
+    if (S <= 0) S = (int)std::max<int64_t>(1, ((int64_t)1 << 21) / npix);
+    S = (int)std::min<int64_t>(std::min<int64_t>(S, n_samples), std::max<int64_t>(1, ((int64_t)1 << 27) / ((int64_t)npix * K)));
+    const size_t P = (size_t)S * npix;
+
+    size_t sizes[28] = {0};
+    sizes[0] = sizes[1] = sizes[3] = sizes[4] = P * sizeof(f4);
+    sizes[2] = P * sizeof(HitRec);
+    sizes[5] = sizes[11] = P * 4;
+    sizes[6] = sizes[7] = sizes[8] = sizes[9] = P * K * sizeof(f4);
+    sizes[10] = P * K * sizeof(HitRec);
+    sizes[12] = sizes[13] = P * 4;
+    sizes[14] = P * K * 4;
+    sizes[17] = kCntTotal * 4 + 64;
+    if (Dl > 0) {
+        sizes[15] = sizes[16] = P * 4;
+        sizes[18] = sizes[19] = sizes[20] = P * Dl * sizeof(f4);
+        sizes[21] = sizes[22] = sizes[24] = P * sizeof(f4);
+        sizes[23] = P * sizeof(HitRec);
+    }
+    static_assert(sizeof(dc.wf) / sizeof(dc.wf[0]) >= 25, "wf buffer table too small");
+    for (int i = 0; i < 25; i++)
+        if (sizes[i]) WF_TRY(dc.wf[i].reserve(sizes[i]));
+    WfBuffers b;
+    memset(&b, 0, sizeof(b));
+    b.path_o = dc.wf[0].as<f4>(); b.path_d = dc.wf[1].as<f4>(); b.path_hit = dc.wf[2].as<HitRec>();
+    b.path_T = dc.wf[3].as<f4>(); b.path_rad = dc.wf[4].as<f4>(); b.path_rng = dc.wf[5].as<uint32_t>();
+    b.sh_o = dc.wf[6].as<f4>(); b.sh_d = dc.wf[7].as<f4>(); b.sh_target = dc.wf[8].as<f4>(); b.sh_contrib = dc.wf[9].as<f4>();
+    b.sh_hit = dc.wf[10].as<HitRec>(); b.sh_mask = dc.wf[11].as<uint32_t>();
+    b.q_cam[0] = dc.wf[12].as<int>(); b.q_cam[1] = dc.wf[13].as<int>(); b.q_shadow = dc.wf[14].as<int>();
+    b.q_light[0] = dc.wf[15].as<int>(); b.q_light[1] = dc.wf[16].as<int>();
+    b.counts = dc.wf[17].as<int>();
+    b.totals = reinterpret_cast<unsigned long long *>(dc.wf[17].as<char>() + kCntTotal * 4 + 8);
+    b.lv_pos = dc.wf[18].as<f4>(); b.lv_nrm = dc.wf[19].as<f4>(); b.lv_T = dc.wf[20].as<f4>();
+    b.l_o = dc.wf[21].as<f4>(); b.l_d = dc.wf[22].as<f4>(); b.l_hit = dc.wf[23].as<HitRec>(); b.l_state = dc.wf[24].as<f4>();
+
+    dc.events.reset();
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ext_ev;
+    hipStream_t sm = dc.stream;
+    WF_TRY(hipMemsetAsync(dc.wf[17].p, 0, sizes[17], sm));
+    hipEvent_t ev_begin = dc.events.next(), ev_end = dc.events.next();
+    WF_TRY(hipEventRecord(ev_begin, sm));
+
+    auto extend = [&](const f4 *ro, const f4 *rd, const int *queue, const int *count, HitRec *hits, size_t n_max) {
+        hipEvent_t a = dc.events.next(), e = dc.events.next();
+        (void)hipEventRecord(a, sm);
+        hipLaunchKernelGGL(k_extend<false>, dim3(extend_grid(dc, (int64_t)n_max)), dim3(kExtendBlock), 0, sm, dc.view, ro, rd,
+                           queue, count, 0, hits, (unsigned long long *)nullptr);
+        (void)hipEventRecord(e, sm);
+        ext_ev.emplace_back(a, e);
+    };
+    const int path_grid = (int)std::min<size_t>((P + kBlock - 1) / kBlock, (size_t)dc.num_cus * 16);
+
+    PassParams pp;
+    pp.W = cfg.width; pp.H = cfg.height; pp.npix = npix; pp.spp = cfg.spp; pp.sample_stride = stride;
+    pp.Dc = Dc; pp.Dl = Dl; pp.K = K; pp.use_env = cfg.use_envmap ? 1 : 0; pp.seed = cfg.seed;
+    for (int64_t done = 0; done < n_samples; done += S) {
+        pp.n_slots = (int)std::min<int64_t>(S, n_samples - done);
+        pp.sample0 = cfg.sample_begin + (int)done * stride;
+        const size_t np = (size_t)pp.n_slots * npix;
+        const unsigned full_grid = (unsigned)((np + kBlock - 1) / kBlock);
+        WF_TRY(hipMemsetAsync(b.counts, 0, kCntTotal * 4, sm));
+        hipLaunchKernelGGL(k_raygen, dim3(full_grid), dim3(kBlock), 0, sm, dc.view, pp, b);
+        if (Dl > 0) {
+            hipLaunchKernelGGL(k_lightgen, dim3(full_grid), dim3(kBlock), 0, sm, dc.view, pp, b);
+            for (int i = 0; i < Dl; i++) {
+                extend(b.l_o, b.l_d, b.q_light[i & 1], &b.counts[kCntLight + i], b.l_hit, np);
+                hipLaunchKernelGGL(k_light_shade, dim3(path_grid), dim3(kBlock), 0, sm, dc.view, pp, b, i);
+            }
+        }
+        for (int i = 0; i < Dc; i++) {
+            extend(b.path_o, b.path_d, b.q_cam[i & 1], &b.counts[kCntCam + i], b.path_hit, np);
+            hipLaunchKernelGGL(k_shade, dim3(path_grid), dim3(kBlock), 0, sm, dc.view, pp, b, i);
+            extend(b.sh_o, b.sh_d, b.q_shadow, &b.counts[kCntShadow + i], b.sh_hit, np * K);
+            hipLaunchKernelGGL(k_resolve, dim3(path_grid), dim3(kBlock), 0, sm, pp, b, i);
+            // the shadow queue is refilled from slot 0 by the next vertex: its count lives in its own slot
+        }
+        hipLaunchKernelGGL(k_accumulate, dim3((unsigned)((npix + kBlock - 1) / kBlock)), dim3(kBlock), 0, sm, pp, b, d_accum);
+        hipLaunchKernelGGL(k_tally, dim3(1), dim3(64), 0, sm, b, Dc, Dl);
+        WF_TRY(hipGetLastError());
+    }
+    WF_TRY(hipEventRecord(ev_end, sm));
+    WF_TRY(hipStreamSynchronize(sm));
+    if (st) {
+        unsigned long long tot[3] = {0, 0, 0};
+        WF_TRY(hipMemcpy(tot, b.totals, sizeof(tot), hipMemcpyDeviceToHost));
+        float ms = 0.f;
+        WF_TRY(hipEventElapsedTime(&ms, ev_begin, ev_end));
+        double ms_ext = 0.0;
+        for (auto &pr : ext_ev) {
+            float m = 0.f;
+            WF_TRY(hipEventElapsedTime(&m, pr.first, pr.second));
+            ms_ext += m;
+        }
+        st->rays_camera = (int64_t)tot[0];
+        st->rays_shadow = (int64_t)tot[1];
+        st->rays_light = (int64_t)tot[2];
+        st->rays_total = st->rays_camera + st->rays_shadow + st->rays_light;
+        st->samples = n_samples * npix;
+        st->extend_launches = (int64_t)ext_ev.size();
+        st->ms_total = ms;
+        st->ms_extend = ms_ext;
+        st->ms_other = ms - ms_ext;
+    }
+    return 0;
+}
+
 }  // namespace mipt

@@ -17,6 +17,7 @@
  *   Q17 light index is clamped to nLights-1.
  *   RNG is Philox4x32-10 keyed on (seed, pixel, sample) instead of cuRAND XORWOW
  *       (mandated by BASELINE.json north_star); uniforms are in (0,1] like curand_uniform.
+ *   sinf/cosf in Light::randomSampleRay use one fixed fp32 polynomial evaluation (see fixed_sinf).
  *   kd build: a node with no in-bounds split candidate or zero width becomes a leaf
  *       (the reference reads out of bounds / divides 0/0 there, mesh.cu:72-78).
  */
@@ -715,12 +716,49 @@ inline V3 radiance_at(const Light &l, V3 p) {
     if (d2 < EPS) d2 = EPS;
     return l.power / d2 / 4.0f / PI;
 }
+// sinf/cosf of light.cuh:35-38, argument in [0, 2*pi].  The last ulp of these functions is
+// implementation-defined on every platform (CUDA's included); the build fixes one evaluation --
+// Cody-Waite reduction by pi/4 and the classic single-precision minimax polynomials -- so that the
+// GPU and this oracle agree bit for bit.  Restated here independently of the product header.
+inline void trig_reduce(float x, int &j, float &r) {
+    j = (int)(x * 1.27323954473516f);
+    if (j & 1) j += 1;
+    float y = (float)j;
+    r = ((x - y * 0.78515625f) - y * 2.4187564849853515625e-4f) - y * 3.77489497744594108e-8f;
+}
+inline float trig_sin_kernel(float r) {
+    float z = r * r;
+    return ((-1.9515295891e-4f * z + 8.3321608736e-3f) * z - 1.6666654611e-1f) * z * r + r;
+}
+inline float trig_cos_kernel(float r) {
+    float z = r * r;
+    return ((2.443315711809948e-5f * z - 1.388731625493765e-3f) * z + 4.166664568298827e-2f) * z * z - 0.5f * z + 1.0f;
+}
+inline float fixed_sinf(float x) {
+    int j; float r;
+    trig_reduce(x, j, r);
+    j &= 7;
+    float sign = 1.0f;
+    if (j > 3) { sign = -1.0f; j -= 4; }
+    float y = (j == 1 || j == 2) ? trig_cos_kernel(r) : trig_sin_kernel(r);
+    return sign * y;
+}
+inline float fixed_cosf(float x) {
+    int j; float r;
+    trig_reduce(x, j, r);
+    j &= 7;
+    float sign = 1.0f;
+    if (j > 3) { sign = -1.0f; j -= 4; }
+    if (j > 1) sign = -sign;
+    float y = (j == 1 || j == 2) ? trig_sin_kernel(r) : trig_cos_kernel(r);
+    return sign * y;
+}
 // light.cuh:30-39 (Q12: not uniform on the sphere)
 inline V3 light_sample_dir(Rng &rng) {
     V3 X = mk(0, 0, 1), Y = mk(0, 1, 0), Z = mk(1, 0, 0);
     float alpha = rng.u() * 2.0f * PI;
     float beta = rng.u() * 2.0f * PI;
-    return normalize((X * cosf(alpha) + Z * sinf(alpha)) * sinf(beta) + Y * cosf(beta));
+    return normalize((X * fixed_cosf(alpha) + Z * fixed_sinf(alpha)) * fixed_sinf(beta) + Y * fixed_cosf(beta));
 }
 // samplers.cuh:8-23 (rejection sampling in the unit disc; frame from N)
 inline float sample_diffuse(V3 N, V3 &out, Rng &rng) {
@@ -1147,6 +1185,7 @@ void orc_camera_ray(orc_scene *s, float X, float Y, int W, int H, float o[3], fl
     Ray r = camera_ray(s->cam, X, Y, W, H);
     o[0] = r.o.x; o[1] = r.o.y; o[2] = r.o.z; d[0] = r.d.x; d[1] = r.d.y; d[2] = r.d.z;
 }
+void orc_sincos(float x, float *s, float *c) { *s = fixed_sinf(x); *c = fixed_cosf(x); }
 void orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) { philox4x32_10(ctr, key, out); }
 float orc_rng_uniform(uint32_t seed, uint32_t pixel, uint32_t sample, uint32_t draw) {
     Rng r(seed, pixel, sample);

@@ -83,6 +83,7 @@ int orc_box_contains(const float box6[6], const float p[3]);
 float orc_plane_intersect(const float point[3], const float normal_unit[3], const float o[3], const float d_unit[3]);
 float orc_sphere_intersect(const float center[3], float radius, const float o[3], const float d_unit[3]);
 void orc_camera_ray(orc_scene *, float X, float Y, int W, int H, float o[3], float d[3]);
+void orc_sincos(float x, float *s, float *c);
 void orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
 float orc_rng_uniform(uint32_t seed, uint32_t pixel, uint32_t sample, uint32_t draw);
 int orc_env_lookup(orc_scene *, const float *dirs, int64_t n, float *rgb, int32_t *face, int32_t *pos);
