@@ -13,7 +13,7 @@ class RenderConfig(C.Structure):
         ("width", C.c_int32), ("height", C.c_int32), ("spp", C.c_int32), ("cam_depth", C.c_int32),
         ("light_depth", C.c_int32), ("use_envmap", C.c_int32), ("seed", C.c_uint32),
         ("sample_begin", C.c_int32), ("sample_end", C.c_int32), ("sample_stride", C.c_int32),
-        ("samples_per_pass", C.c_int32),
+        ("samples_per_pass", C.c_int32), ("flags", C.c_int32),
     ]
 
 

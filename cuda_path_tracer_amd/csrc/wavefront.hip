@@ -445,14 +445,20 @@ int wavefront_render(const HostScene &hs, DeviceCtx &dc, const mipt_render_confi
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ext_ev;
     hipStream_t sm = dc.stream;
     WF_TRY(hipMemsetAsync(dc.wf[17].p, 0, sizes[17], sm));
+    const bool count_mode = (cfg.flags & MIPT_FLAG_COUNTERS) != 0;
+    if (count_mode) WF_TRY(hipMemsetAsync(dc.counters.p, 0, 64, sm));
     hipEvent_t ev_begin = dc.events.next(), ev_end = dc.events.next();
     WF_TRY(hipEventRecord(ev_begin, sm));
 
     auto extend = [&](const f4 *ro, const f4 *rd, const int *queue, const int *count, HitRec *hits, size_t n_max) {
         hipEvent_t a = dc.events.next(), e = dc.events.next();
         (void)hipEventRecord(a, sm);
-        hipLaunchKernelGGL(k_extend<false>, dim3(extend_grid(dc, (int64_t)n_max)), dim3(kExtendBlock), 0, sm, dc.view, ro, rd,
-                           queue, count, 0, hits, (unsigned long long *)nullptr);
+        if (count_mode)
+            hipLaunchKernelGGL(k_extend<true>, dim3(extend_grid(dc, (int64_t)n_max)), dim3(kExtendBlock), 0, sm, dc.view, ro,
+                               rd, queue, count, 0, hits, dc.counters.as<unsigned long long>());
+        else
+            hipLaunchKernelGGL(k_extend<false>, dim3(extend_grid(dc, (int64_t)n_max)), dim3(kExtendBlock), 0, sm, dc.view, ro,
+                               rd, queue, count, 0, hits, (unsigned long long *)nullptr);
         (void)hipEventRecord(e, sm);
         ext_ev.emplace_back(a, e);
     };
@@ -508,6 +514,12 @@ int wavefront_render(const HostScene &hs, DeviceCtx &dc, const mipt_render_confi
         st->ms_total = ms;
         st->ms_extend = ms_ext;
         st->ms_other = ms - ms_ext;
+        if (count_mode) {
+            unsigned long long c[8] = {0};
+            WF_TRY(hipMemcpy(c, dc.counters.p, sizeof(c), hipMemcpyDeviceToHost));
+            st->ctr_nodes = (int64_t)c[0]; st->ctr_pops = (int64_t)c[1]; st->ctr_refs = (int64_t)c[2];
+            st->ctr_tris = (int64_t)c[3]; st->ctr_hits = (int64_t)c[4];
+        }
     }
     return 0;
 }

@@ -31,6 +31,7 @@ typedef struct mipt_render_config {
     uint32_t seed;           /* counter-based RNG key (replaces curand_init, kernel.cu:331)       */
     int32_t sample_begin, sample_end, sample_stride; /* this call renders s = begin, begin+stride, ... < end */
     int32_t samples_per_pass; /* samples of every pixel in flight per wavefront pass; 0 = auto    */
+    int32_t flags;            /* MIPT_FLAG_COUNTERS: also fill the traversal counters (slower kernel) */
 } mipt_render_config;
 
 /* Replaces the wall-clock print of kernel.cu:395-412 with per-stage GPU timings and ray counts. */
