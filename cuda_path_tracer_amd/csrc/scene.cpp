@@ -320,6 +320,7 @@ bool HostScene::pack(int n_threads, std::string &err) {
     L.nodes = section((size_t)total_nodes * sizeof(KdNode));
     L.boxes = section((size_t)total_nodes * 32);
     L.refs = section((size_t)total_refs * 4);
+    L.leaf_planes = section((size_t)total_refs * 16);
     L.tri_pos = section((size_t)total_tris * 48);
     L.tri_nrm = section((size_t)total_tris * 48);
     L.meshes = section(meshes.size() * sizeof(DMesh));
@@ -345,6 +346,16 @@ bool HostScene::pack(int n_threads, std::string &err) {
         memcpy(A + L.boxes + (size_t)hm.node_base * 32, t.boxes.data(), (size_t)hm.n_nodes * 32);
         int32_t *refs = reinterpret_cast<int32_t *>(A + L.refs) + hm.ref_base;
         for (int64_t i = 0; i < hm.n_refs; i++) refs[i] = t.refs[(size_t)i] + (int32_t)hm.tri_base;
+        // leaf-ordered plane records: N = cross(b-a, c-a), dd = -dot(N, a) exactly as Triangle::intersect
+        // evaluates them per candidate (mesh.cuh:40-42,52); same fp32 operations, done once here
+        float *lp = reinterpret_cast<float *>(A + L.leaf_planes) + (size_t)hm.ref_base * 4;
+        for (int64_t i = 0; i < hm.n_refs; i++) {
+            const float *v = hm.pos.data() + (size_t)t.refs[(size_t)i] * 9;
+            const f3 a = mk3(v[0], v[1], v[2]), b = mk3(v[3], v[4], v[5]), c = mk3(v[6], v[7], v[8]);
+            const f3 N = cross3(b - a, c - a);
+            lp[4 * i] = N.x; lp[4 * i + 1] = N.y; lp[4 * i + 2] = N.z;
+            lp[4 * i + 3] = -dot3(N, a);
+        }
         float *tp = reinterpret_cast<float *>(A + L.tri_pos) + (size_t)hm.tri_base * 12;
         float *tn = reinterpret_cast<float *>(A + L.tri_nrm) + (size_t)hm.tri_base * 12;
         for (int64_t i = 0; i < hm.n_tris * 3; i++) {
@@ -399,6 +410,7 @@ DScene HostScene::view(const void *base_v) const {
     d.nodes = reinterpret_cast<const KdNode *>(base + layout.nodes);
     d.boxes = reinterpret_cast<const f4 *>(base + layout.boxes);
     d.refs = reinterpret_cast<const int32_t *>(base + layout.refs);
+    d.leaf_planes = reinterpret_cast<const f4 *>(base + layout.leaf_planes);
     d.tri_pos = reinterpret_cast<const f4 *>(base + layout.tri_pos);
     d.tri_nrm = reinterpret_cast<const f4 *>(base + layout.tri_nrm);
     d.meshes = reinterpret_cast<const DMesh *>(base + layout.meshes);

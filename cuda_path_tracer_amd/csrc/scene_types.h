@@ -8,6 +8,8 @@
 //                               (right child = own index + 1); leaf: x = first ref, y = 3<<30 | count
 //   boxes    float4[2*n_nodes]  (minX,maxX,minY,maxY) (minZ,maxZ,-,-): read for the root and on stack pops only
 //   refs     int32[n_refs]      leaf triangle index lists (global triangle ids, leaf order = input order)
+//   leaf_planes float4[n_refs]   plane record (N, -N.a) of each reference, contiguous per leaf: the leaf loop
+//                               streams these 16-byte records and touches vertices only for survivors
 //   tri_pos  float4[3*n_tris]   vertex positions a,b,c (w unused) -- three 16-byte loads per candidate
 //   tri_nrm  float4[3*n_tris]   vertex normals, fetched once for the winning triangle
 //   meshes / spheres / planes / lights / materials: small tables read through scalar loads
@@ -48,6 +50,7 @@ struct DScene {
     const KdNode *nodes;
     const f4 *boxes;
     const int32_t *refs;
+    const f4 *leaf_planes;  // per leaf reference: (N.xyz, -dot(N,a)) of that triangle, in leaf order
     const f4 *tri_pos;
     const f4 *tri_nrm;
     const DMesh *meshes;

@@ -75,28 +75,31 @@ PT_HD void load_slab(const DScene &sc, int node, f3 o, f3 d, SlabBox &b) {
     b.thi[2] = (b.hi[2] - o.z) / d.z;
 }
 
-// Triangle::intersect up to the inside test (mesh.cuh:36-90) with the leaf acceptance of
-// Mesh::intersect (mesh.cuh:293-296) folded in.  Returns true and updates best when accepted.
-PT_HD bool leaf_candidate(f3 a, f3 b, f3 c, f3 o, f3 d, const SlabBox &box, float &best) {
-    const f3 ab = b - a, ac = c - a;
-    const f3 N = cross3(ab, ac);
+// Triangle::intersect (mesh.cuh:36-90) split in two.  Part 1 needs only the plane record (N, dd) that the
+// packer precomputed with the reference's own expressions (mesh.cuh:40-42,52): plane distance, the
+// acceptance conditions of Mesh::intersect (mesh.cuh:293-296: t > 0, t < best, point inside the leaf box, Q8)
+// and the parallel test (Q3).  Returns the candidate's t, or -1 when it cannot be accepted.
+PT_HD float plane_candidate(f4 pl, f3 o, f3 d, const SlabBox &box, float best) {
+    const f3 N = mk3(pl.x, pl.y, pl.z);
     const float nd = dot3(N, d);
-    if (fabsf(nd) < kEps) return false;  // Q3
-    const float dd = -dot3(N, a);
-    const float t = -(dot3(N, o) + dd) / nd;
-    if (!(t > 0.0f)) return false;                    // t<0 -> raw negative, t==0 -> fails "hit.t > 0"
-    if (!(best < 0.0f || t < best)) return false;     // cannot replace the current best
+    if (fabsf(nd) < kEps) return -1.0f;  // Q3
+    const float t = -(dot3(N, o) + pl.w) / nd;
+    if (!(t > 0.0f)) return -1.0f;                 // t<0 -> raw negative, t==0 -> fails "hit.t > 0"
+    if (!(best < 0.0f || t < best)) return -1.0f;  // cannot replace the current best
     const f3 P = o + d * t;
-    if (!point_in_box(P, box.lo[0], box.hi[0], box.lo[1], box.hi[1], box.lo[2], box.hi[2])) return false;  // Q8
-    f3 C = cross3(ab, P - a);
+    if (!point_in_box(P, box.lo[0], box.hi[0], box.lo[1], box.hi[1], box.lo[2], box.hi[2])) return -1.0f;
+    return t;
+}
+// Part 2: the three inside-outside edge tests (mesh.cuh:61-88) for a surviving candidate.
+PT_HD bool inside_triangle(f4 pl, f3 a, f3 b, f3 c, f3 o, f3 d, float t) {
+    const f3 N = mk3(pl.x, pl.y, pl.z);
+    const f3 P = o + d * t;
+    f3 C = cross3(b - a, P - a);
     if (dot3(N, C) < 0.0f) return false;
-    const f3 bc = c - b;
-    C = cross3(bc, P - b);
+    C = cross3(c - b, P - b);
     if (dot3(N, C) < 0.0f) return false;
-    const f3 ca = a - c;
-    C = cross3(ca, P - c);
+    C = cross3(a - c, P - c);
     if (dot3(N, C) < 0.0f) return false;
-    best = t;
     return true;
 }
 
@@ -155,10 +158,25 @@ PT_HD void mesh_closest(const DScene &sc, int root, f3 o, f3 d, Stack &stk, floa
         float bt = -1.0f;
         int bi = -1;
         if (COUNT) { ctr.refs += count; ctr.tris += count; }
-        for (int i = 0; i < count; i++) {
-            const int tri = sc.refs[first + i];
-            const f4 pa = sc.tri_pos[3 * (size_t)tri], pb = sc.tri_pos[3 * (size_t)tri + 1], pc = sc.tri_pos[3 * (size_t)tri + 2];
-            if (leaf_candidate(mk3(pa.x, pa.y, pa.z), mk3(pb.x, pb.y, pb.z), mk3(pc.x, pc.y, pc.z), o, d, cur, bt)) bi = tri;
+        // The 16-byte plane records of a leaf are contiguous: fetch four ahead of use (clamped, so every load is
+        // in bounds), then evaluate them in leaf order -- the sequential "t < best" rule keeps the earliest of ties.
+        for (int i0 = 0; i0 < count; i0 += 4) {
+            f4 pl[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) pl[k] = sc.leaf_planes[first + ((i0 + k < count) ? i0 + k : count - 1)];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const float t = (i0 + k < count) ? plane_candidate(pl[k], o, d, cur, bt) : -1.0f;
+                if (t > 0.0f) {
+                    const int tri = sc.refs[first + i0 + k];
+                    const f4 pa = sc.tri_pos[3 * (size_t)tri], pb = sc.tri_pos[3 * (size_t)tri + 1],
+                             pc = sc.tri_pos[3 * (size_t)tri + 2];
+                    if (inside_triangle(pl[k], mk3(pa.x, pa.y, pa.z), mk3(pb.x, pb.y, pb.z), mk3(pc.x, pc.y, pc.z), o, d, t)) {
+                        bt = t;
+                        bi = tri;
+                    }
+                }
+            }
         }
         if (bt > 0.0f) {
             best_t = bt;
