@@ -6,6 +6,7 @@
 #include <algorithm>
 #include <chrono>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <thread>
@@ -208,7 +209,10 @@ int mipt_scene_commit(mipt_scene *s, const int *device_ids, int n_devices) {
         HIP_TRY(hipMalloc(&dc.arena, s->host.arena.size()));
         HIP_TRY(hipMemcpyAsync(dc.arena, s->host.arena.data(), s->host.arena.size(), hipMemcpyHostToDevice, dc.stream));
         HIP_TRY(hipStreamSynchronize(dc.stream));
-        HIP_TRY(dc.counters.reserve(64));
+        HIP_TRY(dc.counters.reserve(128));  // [0,64) traversal counters, [64,128) work cursor of the persistent kernel
+        dc.extend_blocks_per_cu = query_extend_blocks_per_cu();
+        const char *ev = getenv("MIPT_EXTEND");
+        dc.extend_simple = ev && std::string(ev) == "simple";
         dc.view = s->host.view(dc.arena);
         s->devs.push_back(dc);
     }
@@ -232,21 +236,14 @@ int mipt_trace_closest_device(mipt_scene *s, int slot, const float *d_ray_o, con
     dc.events.reset();
     hipEvent_t e0 = dc.events.next(), e1 = dc.events.next(), e2 = dc.events.next(), e3 = dc.events.next();
     const bool count = (flags & MIPT_FLAG_COUNTERS) != 0;
-    if (count) HIP_TRY(hipMemsetAsync(dc.counters.p, 0, 64, dc.stream));
+    HIP_TRY(hipMemsetAsync(dc.counters.p, 0, 128, dc.stream));
     const int blocks = (int)((n + 255) / 256);
     HIP_TRY(hipEventRecord(e0, dc.stream));
     hipLaunchKernelGGL(k_make_rays, dim3(blocks), dim3(256), 0, dc.stream, d_ray_o, d_ray_d, n, dc.ray_o.as<f4>(),
                        dc.ray_d.as<f4>());
     HIP_TRY(hipEventRecord(e1, dc.stream));
-    const int grid = extend_grid(dc, n);
-    if (count)
-        hipLaunchKernelGGL(k_extend<true>, dim3(grid), dim3(kExtendBlock), 0, dc.stream, dc.view, dc.ray_o.as<f4>(),
-                           dc.ray_d.as<f4>(), (const int *)nullptr, (const int *)nullptr, (int)n, dc.hits.as<HitRec>(),
-                           dc.counters.as<unsigned long long>());
-    else
-        hipLaunchKernelGGL(k_extend<false>, dim3(grid), dim3(kExtendBlock), 0, dc.stream, dc.view, dc.ray_o.as<f4>(),
-                           dc.ray_d.as<f4>(), (const int *)nullptr, (const int *)nullptr, (int)n, dc.hits.as<HitRec>(),
-                           (unsigned long long *)nullptr);
+    launch_extend(dc, count, dc.ray_o.as<f4>(), dc.ray_d.as<f4>(), nullptr, nullptr, (int)n, n, dc.hits.as<HitRec>(),
+                  reinterpret_cast<int *>(dc.counters.as<char>() + 64), dc.counters.as<unsigned long long>());
     HIP_TRY(hipEventRecord(e2, dc.stream));
     hipLaunchKernelGGL(k_split_hits, dim3(blocks), dim3(256), 0, dc.stream, dc.hits.as<HitRec>(), n, d_prim, d_t);
     HIP_TRY(hipEventRecord(e3, dc.stream));

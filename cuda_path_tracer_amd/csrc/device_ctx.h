@@ -58,6 +58,8 @@ struct DeviceCtx {
     void *arena = nullptr;
     DScene view;
     int num_cus = 256;
+    int extend_blocks_per_cu = 4;  // resident blocks of the persistent extend kernel
+    bool extend_simple = false;    // MIPT_EXTEND=simple: grid-stride reference kernel (A/B timing)
     // closest-hit work buffers
     DevBuf ray_o, ray_d, hits, io_a, io_b, io_c, io_d, counters;
     // wavefront work buffers (see wavefront.hip)

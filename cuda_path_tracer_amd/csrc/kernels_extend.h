@@ -1,10 +1,13 @@
 // kernels_extend.h -- the `extend` stage: kd-tree closest hit over a ray queue (gfx950, wave64).
 //
-// One lane = one ray (T3/T4 of SURVEY.md 8a).  The block is 256 lanes = 4 waves; the traversal
-// stack is an LDS array laid out [slot][lane] so that a wave's 64 lanes hit 64 consecutive banks.
-// The grid is sized to the chip (256 CUs x resident blocks) and strides over the queue, so the
-// same launch shape serves 4K-pixel frames and the shrinking queues of later bounces, with the
-// ray count read from device memory (no host round trip between bounces).
+// One lane = one ray (T3/T4 of SURVEY.md 8a).  Rays differ wildly in cost (a ray of the 1.3M-triangle test mesh
+// visits 1..40 leaves), so the kernel is PERSISTENT: the grid is exactly the number of resident waves, every
+// lane is a small state machine (start mesh -> descend -> leaf -> pop / next mesh -> finish), and a wave
+// refills its idle lanes from a global work counter (ballot + mbcnt rank + one atomic per refill) as soon as
+// enough of them have finished.  The unit of re-convergence is one leaf visit, so a lane never waits for a
+// neighbour's whole ray, only for its current descent / leaf.
+// The traversal stack is an LDS array laid out [slot][lane]: a wave's 64 lanes hit 64 consecutive banks.
+// The ray count is read from device memory (no host round trip between bounces of the wavefront tracer).
 #pragma once
 #include <hip/hip_runtime.h>
 #include "device_ctx.h"
@@ -13,6 +16,7 @@
 namespace mipt {
 
 constexpr int kExtendBlock = 256;
+constexpr int kRefillLanes = 12;  // refill a wave once this many lanes are idle (or all of them)
 
 struct LdsStack {
     int *col;  // &stack[threadIdx.x]
@@ -26,13 +30,134 @@ __device__ __forceinline__ unsigned int wave_sum(unsigned int v) {
     return v;
 }
 
+__device__ __forceinline__ void flush_counters(const TravCounters &tc, unsigned int hit_tris, unsigned long long *ctr) {
+    const unsigned int a = wave_sum(tc.nodes), b = wave_sum(tc.pops), c = wave_sum(tc.refs), d = wave_sum(tc.tris),
+                       e = wave_sum(hit_tris);
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(&ctr[0], (unsigned long long)a);
+        atomicAdd(&ctr[1], (unsigned long long)b);
+        atomicAdd(&ctr[2], (unsigned long long)c);
+        atomicAdd(&ctr[3], (unsigned long long)d);
+        atomicAdd(&ctr[4], (unsigned long long)e);
+    }
+}
+
 // rays: o/d as float4 (w unused), d already normalised by the Ray constructor rule (ray.cuh:10).
-// queue: optional indirection (slot ids); count_ptr: optional device-side ray count.
+// queue: optional indirection (slot ids); count_ptr: optional device-side ray count; work: zeroed counter.
 template <bool COUNT>
 __global__ __launch_bounds__(kExtendBlock) void k_extend(DScene sc, const f4 *__restrict__ ray_o,
                                                          const f4 *__restrict__ ray_d, const int *__restrict__ queue,
                                                          const int *__restrict__ count_ptr, int n_fixed,
-                                                         HitRec *__restrict__ hits, unsigned long long *ctr) {
+                                                         HitRec *__restrict__ hits, int *__restrict__ work,
+                                                         unsigned long long *ctr) {
+    __shared__ int stack_mem[kStackDepth * kExtendBlock];
+    LdsStack stk{stack_mem + threadIdx.x};
+    const int n = count_ptr ? *count_ptr : n_fixed;
+    const int lane = (int)(threadIdx.x & 63u);
+    TravCounters tc = {0u, 0u, 0u, 0u};
+    unsigned int hit_tris = 0;
+
+    bool has_ray = false, exhausted = false;
+    bool start_mesh = false;  // lane must open mesh `m` (or finish the ray when m == n_meshes)
+    int slot = 0, m = 0, node = 0, sp = 0, prim = -1;
+    float best = -1.0f;
+    f3 o = mk3(0.f, 0.f, 0.f), d = mk3(0.f, 0.f, 1.f);
+    SlabBox cur;
+#pragma unroll
+    for (int k = 0; k < 3; k++) cur.lo[k] = cur.hi[k] = cur.tlo[k] = cur.thi[k] = 0.f;
+
+    for (;;) {
+        // ---- refill idle lanes from the global work counter --------------------------------------------
+        const unsigned long long idle = __ballot(!has_ray);
+        if (idle != 0ull && !exhausted) {
+            const int n_idle = __popcll(idle);
+            if (n_idle >= kRefillLanes || n_idle == 64) {
+                const int leader = __ffsll((long long)idle) - 1;
+                int base = 0;
+                if (lane == leader) base = atomicAdd(work, n_idle);
+                base = __shfl(base, leader, 64);
+                const int rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned int)(idle >> 32),
+                                                                __builtin_amdgcn_mbcnt_lo((unsigned int)idle, 0u));
+                if (!has_ray && base + rank < n) {
+                    slot = queue ? queue[base + rank] : base + rank;
+                    const f4 o4 = ray_o[slot], d4 = ray_d[slot];
+                    o = mk3(o4.x, o4.y, o4.z);
+                    d = mk3(d4.x, d4.y, d4.z);
+                    best = -1.0f;
+                    prim = -1;
+                    m = 0;
+                    start_mesh = true;
+                    has_ray = true;
+                }
+                if (base + n_idle >= n) exhausted = true;  // wave-uniform: base and n_idle are
+            }
+        }
+        if (__ballot(has_ray) == 0ull) {
+            if (exhausted) break;
+            continue;
+        }
+        if (!has_ray) continue;
+
+        // ---- one step of the lane's state machine --------------------------------------------------------
+        if (start_mesh) {
+            if (m >= sc.n_meshes) {  // Scene::firstIntersect tail: spheres, then planes (kernel.cu:151-158)
+                for (int i = 0; i < sc.n_spheres; i++) {
+                    const f4 s = sc.spheres[2 * i];
+                    const float t = sphere_t(mk3(s.x, s.y, s.z), s.w, o, d);
+                    if (t > 0.0f && (best < 0.0f || t < best)) { best = t; prim = sc.total_tris + i; }
+                }
+                for (int i = 0; i < sc.n_planes; i++) {
+                    const f4 p = sc.planes[2 * i], pn = sc.planes[2 * i + 1];
+                    const float t = plane_t(mk3(p.x, p.y, p.z), mk3(pn.x, pn.y, pn.z), o, d);
+                    if (t > 0.0f && (best < 0.0f || t < best)) { best = t; prim = sc.total_tris + sc.n_spheres + i; }
+                }
+                HitRec h;
+                h.t = best;
+                h.prim = prim;
+                hits[slot] = h;
+                if (COUNT) hit_tris += (prim >= 0 && prim < sc.total_tris) ? 1u : 0u;
+                has_ray = false;
+                continue;
+            }
+            node = sc.meshes[m].root;
+            load_slab(sc, node, o, d, cur);
+            if (!(slab_hit(cur, o, d) > 0.0f)) {  // mesh.cuh:254: the ray misses the mesh's root box
+                m++;
+                continue;
+            }
+            sp = 0;
+            start_mesh = false;
+            if (COUNT) { tc.pops++; tc.nodes++; }
+        }
+        const KdNode leaf = descend_to_leaf<LdsStack, COUNT>(sc, o, d, cur, node, sp, stk, tc);
+        float bt;
+        int bi;
+        leaf_closest<COUNT>(sc, leaf, o, d, cur, bt, bi, tc);
+        if (bt > 0.0f) {  // mesh.cuh:300 first accepting leaf ends this mesh; kernel.cu:149 merge (strict '<')
+            if (best < 0.0f || bt < best) { best = bt; prim = bi; }
+            m++;
+            start_mesh = true;
+        } else if (sp == 0 || sp > kStackDepth) {  // stack empty (or, unreachable, overflowed): mesh missed
+            m++;
+            start_mesh = true;
+        } else {
+            sp--;
+            node = stk.pop(sp);
+            load_slab(sc, node, o, d, cur);
+            if (COUNT) { tc.pops++; tc.nodes++; }
+        }
+    }
+    if (COUNT) flush_counters(tc, hit_tris, ctr);
+}
+
+// Reference formulation (one ray start to finish per lane, grid-stride): kept for A/B timing of the
+// persistent kernel in one process (MIPT_EXTEND=simple) and as a second implementation in the parity tests.
+template <bool COUNT>
+__global__ __launch_bounds__(kExtendBlock) void k_extend_simple(DScene sc, const f4 *__restrict__ ray_o,
+                                                                const f4 *__restrict__ ray_d, const int *__restrict__ queue,
+                                                                const int *__restrict__ count_ptr, int n_fixed,
+                                                                HitRec *__restrict__ hits, int *__restrict__ work,
+                                                                unsigned long long *ctr) {
     __shared__ int stack_mem[kStackDepth * kExtendBlock];
     LdsStack stk{stack_mem + threadIdx.x};
     const int n = count_ptr ? *count_ptr : n_fixed;
@@ -50,22 +175,12 @@ __global__ __launch_bounds__(kExtendBlock) void k_extend(DScene sc, const f4 *__
         hits[slot] = h;
         if (COUNT) hit_tris += (prim >= 0 && prim < sc.total_tris) ? 1u : 0u;
     }
-    if (COUNT) {
-        const unsigned int a = wave_sum(tc.nodes), b = wave_sum(tc.pops), c = wave_sum(tc.refs), d = wave_sum(tc.tris),
-                           e = wave_sum(hit_tris);
-        if ((threadIdx.x & 63) == 0) {
-            atomicAdd(&ctr[0], (unsigned long long)a);
-            atomicAdd(&ctr[1], (unsigned long long)b);
-            atomicAdd(&ctr[2], (unsigned long long)c);
-            atomicAdd(&ctr[3], (unsigned long long)d);
-            atomicAdd(&ctr[4], (unsigned long long)e);
-        }
-    }
+    if (COUNT) flush_counters(tc, hit_tris, ctr);
 }
 
 // Ray(o, d) constructor (ray.cuh:10): dir = d * (1/(|d|+eps)).  Packed xyz triples -> float4 pairs.
-static __global__ __launch_bounds__(256) void k_make_rays(const float *__restrict__ o3, const float *__restrict__ d3, int64_t n,
-                                                   f4 *__restrict__ ray_o, f4 *__restrict__ ray_d) {
+static __global__ __launch_bounds__(256) void k_make_rays(const float *__restrict__ o3, const float *__restrict__ d3,
+                                                          int64_t n, f4 *__restrict__ ray_o, f4 *__restrict__ ray_d) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     const f3 o = mk3(o3[3 * i], o3[3 * i + 1], o3[3 * i + 2]);
@@ -74,8 +189,8 @@ static __global__ __launch_bounds__(256) void k_make_rays(const float *__restric
     ray_d[i] = f4{d.x, d.y, d.z, 0.f};
 }
 
-static __global__ __launch_bounds__(256) void k_split_hits(const HitRec *__restrict__ hits, int64_t n, int32_t *__restrict__ prim,
-                                                    float *__restrict__ t) {
+static __global__ __launch_bounds__(256) void k_split_hits(const HitRec *__restrict__ hits, int64_t n,
+                                                           int32_t *__restrict__ prim, float *__restrict__ t) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     const HitRec h = hits[i];
@@ -83,10 +198,35 @@ static __global__ __launch_bounds__(256) void k_split_hits(const HitRec *__restr
     t[i] = h.t;
 }
 
-inline int extend_grid(const DeviceCtx &dc, int64_t n_max) {
+// Launch the extend stage on dc.stream.  `work` must point at a zeroed int (the persistent kernel's ray cursor).
+inline void launch_extend(const DeviceCtx &dc, bool count, const f4 *ro, const f4 *rd, const int *queue, const int *count_ptr,
+                          int n_fixed, int64_t n_max, HitRec *hits, int *work, unsigned long long *ctr) {
+    if (dc.extend_simple) {
+        const int64_t want = (n_max + kExtendBlock - 1) / kExtendBlock;
+        const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(want, (int64_t)dc.num_cus * 8));
+        if (count)
+            hipLaunchKernelGGL(k_extend_simple<true>, dim3(grid), dim3(kExtendBlock), 0, dc.stream, dc.view, ro, rd, queue,
+                               count_ptr, n_fixed, hits, work, ctr);
+        else
+            hipLaunchKernelGGL(k_extend_simple<false>, dim3(grid), dim3(kExtendBlock), 0, dc.stream, dc.view, ro, rd, queue,
+                               count_ptr, n_fixed, hits, work, ctr);
+        return;
+    }
     const int64_t want = (n_max + kExtendBlock - 1) / kExtendBlock;
-    const int64_t cap = (int64_t)dc.num_cus * 8;
-    return (int)std::max<int64_t>(1, std::min(want, cap));
+    const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(want, (int64_t)dc.num_cus * dc.extend_blocks_per_cu));
+    if (count)
+        hipLaunchKernelGGL(k_extend<true>, dim3(grid), dim3(kExtendBlock), 0, dc.stream, dc.view, ro, rd, queue, count_ptr,
+                           n_fixed, hits, work, ctr);
+    else
+        hipLaunchKernelGGL(k_extend<false>, dim3(grid), dim3(kExtendBlock), 0, dc.stream, dc.view, ro, rd, queue, count_ptr,
+                           n_fixed, hits, work, ctr);
+}
+
+// Resident 256-thread blocks per CU of the persistent kernel (occupancy API, capped like the hardware admits).
+inline int query_extend_blocks_per_cu() {
+    int nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_extend<false>, kExtendBlock, 0) != hipSuccess || nb <= 0) nb = 4;
+    return std::min(nb, 8);
 }
 
 }  // namespace mipt

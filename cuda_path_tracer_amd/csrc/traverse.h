@@ -103,7 +103,79 @@ PT_HD bool inside_triangle(f4 pl, f3 a, f3 b, f3 c, f3 o, f3 d, float t) {
     return true;
 }
 
-// Mesh::intersect (mesh.cuh:253-305).  Stack: push(sp, v) / pop(sp) on a per-lane column.
+// Inner loop of Mesh::intersect (mesh.cuh:265-288): walk from `node` down to a leaf, pushing the far child
+// when both children are hit (Q7).  `cur` (bounds + plane parameters of `node`) is updated in place.
+template <class Stack, bool COUNT>
+PT_HD KdNode descend_to_leaf(const DScene &sc, f3 o, f3 d, SlabBox &cur, int &node, int &sp, Stack &stk, TravCounters &ctr) {
+    KdNode nd = sc.nodes[node];
+    while ((nd.b >> 30) != 3u) {
+        const uint32_t ax = nd.b >> 30;
+        const int left = (int)(nd.b & kIdxMask), right = node + 1;
+        const float s = as_f32(nd.a);
+        const float oa = ax == 0 ? o.x : (ax == 1 ? o.y : o.z);
+        const float da = ax == 0 ? d.x : (ax == 1 ? d.y : d.z);
+        const float ts = (s - oa) / da;
+        SlabBox rb = cur, lb = cur;
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            const bool on = ax == (uint32_t)k;
+            rb.lo[k] = on ? s : cur.lo[k];
+            rb.tlo[k] = on ? ts : cur.tlo[k];
+            lb.hi[k] = on ? s : cur.hi[k];
+            lb.thi[k] = on ? ts : cur.thi[k];
+        }
+        const float rt = slab_hit(rb, o, d);  // mesh.cuh:266-269
+        const float lt = slab_hit(lb, o, d);
+        const bool rf = rt < lt;              // Q7: a miss (-1) sorts first
+        const float small_t = rf ? rt : lt, big_t = rf ? lt : rt;
+        const bool go_right = (small_t > 0.0f) ? rf : !rf;  // mesh.cuh:281
+        if ((small_t > 0.0f) & (big_t > 0.0f)) {            // mesh.cuh:285
+            if (sp < kStackDepth) stk.push(sp, rf ? left : right);
+            sp++;
+        }
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            cur.lo[k] = go_right ? rb.lo[k] : cur.lo[k];
+            cur.tlo[k] = go_right ? rb.tlo[k] : cur.tlo[k];
+            cur.hi[k] = go_right ? cur.hi[k] : lb.hi[k];
+            cur.thi[k] = go_right ? cur.thi[k] : lb.thi[k];
+        }
+        node = go_right ? right : left;
+        nd = sc.nodes[node];
+        if (COUNT) ctr.nodes++;
+    }
+    return nd;
+}
+
+// Leaf loop of Mesh::intersect (mesh.cuh:290-299).  The 16-byte plane records of a leaf are contiguous: four
+// are fetched ahead of use (indices clamped, so every load is in bounds) and evaluated in leaf order -- the
+// sequential "t < best" rule keeps the earliest of equal hits.
+template <bool COUNT>
+PT_HD void leaf_closest(const DScene &sc, KdNode nd, f3 o, f3 d, const SlabBox &cur, float &bt, int &bi, TravCounters &ctr) {
+    const int first = (int)nd.a, count = (int)(nd.b & kIdxMask);
+    bt = -1.0f;
+    bi = -1;
+    if (COUNT) { ctr.refs += count; ctr.tris += count; }
+    for (int i0 = 0; i0 < count; i0 += 4) {
+        f4 pl[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) pl[k] = sc.leaf_planes[first + ((i0 + k < count) ? i0 + k : count - 1)];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const float t = (i0 + k < count) ? plane_candidate(pl[k], o, d, cur, bt) : -1.0f;
+            if (t > 0.0f) {
+                const int tri = sc.refs[first + i0 + k];
+                const f4 pa = sc.tri_pos[3 * (size_t)tri], pb = sc.tri_pos[3 * (size_t)tri + 1], pc = sc.tri_pos[3 * (size_t)tri + 2];
+                if (inside_triangle(pl[k], mk3(pa.x, pa.y, pa.z), mk3(pb.x, pb.y, pb.z), mk3(pc.x, pc.y, pc.z), o, d, t)) {
+                    bt = t;
+                    bi = tri;
+                }
+            }
+        }
+    }
+}
+
+// Mesh::intersect (mesh.cuh:253-305), one ray start to finish.  Stack: push(sp, v) / pop(sp) on a per-lane column.
 template <class Stack, bool COUNT>
 PT_HD void mesh_closest(const DScene &sc, int root, f3 o, f3 d, Stack &stk, float &best_t, int &best_tri,
                         TravCounters &ctr) {
@@ -116,69 +188,11 @@ PT_HD void mesh_closest(const DScene &sc, int root, f3 o, f3 d, Stack &stk, floa
     int sp = 0;
     if (COUNT) { ctr.pops++; ctr.nodes++; }
     for (;;) {
-        KdNode nd = sc.nodes[node];
-        while ((nd.b >> 30) != 3u) {  // mesh.cuh:265
-            const uint32_t ax = nd.b >> 30;
-            const int left = (int)(nd.b & kIdxMask), right = node + 1;
-            const float s = as_f32(nd.a);
-            const float oa = ax == 0 ? o.x : (ax == 1 ? o.y : o.z);
-            const float da = ax == 0 ? d.x : (ax == 1 ? d.y : d.z);
-            const float ts = (s - oa) / da;
-            SlabBox rb = cur, lb = cur;
-#pragma unroll
-            for (int k = 0; k < 3; k++) {
-                const bool on = ax == (uint32_t)k;
-                rb.lo[k] = on ? s : cur.lo[k];
-                rb.tlo[k] = on ? ts : cur.tlo[k];
-                lb.hi[k] = on ? s : cur.hi[k];
-                lb.thi[k] = on ? ts : cur.thi[k];
-            }
-            const float rt = slab_hit(rb, o, d);  // mesh.cuh:266-269
-            const float lt = slab_hit(lb, o, d);
-            const bool rf = rt < lt;              // Q7: a miss (-1) sorts first
-            const float small_t = rf ? rt : lt, big_t = rf ? lt : rt;
-            const bool go_right = (small_t > 0.0f) ? rf : !rf;  // mesh.cuh:281
-            if ((small_t > 0.0f) & (big_t > 0.0f)) {            // mesh.cuh:285
-                if (sp < kStackDepth) stk.push(sp, rf ? left : right);
-                sp++;
-            }
-#pragma unroll
-            for (int k = 0; k < 3; k++) {
-                cur.lo[k] = go_right ? rb.lo[k] : cur.lo[k];
-                cur.tlo[k] = go_right ? rb.tlo[k] : cur.tlo[k];
-                cur.hi[k] = go_right ? cur.hi[k] : lb.hi[k];
-                cur.thi[k] = go_right ? cur.thi[k] : lb.thi[k];
-            }
-            node = go_right ? right : left;
-            nd = sc.nodes[node];
-            if (COUNT) ctr.nodes++;
-        }
-        // leaf (mesh.cuh:290-300)
-        const int first = (int)nd.a, count = (int)(nd.b & kIdxMask);
-        float bt = -1.0f;
-        int bi = -1;
-        if (COUNT) { ctr.refs += count; ctr.tris += count; }
-        // The 16-byte plane records of a leaf are contiguous: fetch four ahead of use (clamped, so every load is
-        // in bounds), then evaluate them in leaf order -- the sequential "t < best" rule keeps the earliest of ties.
-        for (int i0 = 0; i0 < count; i0 += 4) {
-            f4 pl[4];
-#pragma unroll
-            for (int k = 0; k < 4; k++) pl[k] = sc.leaf_planes[first + ((i0 + k < count) ? i0 + k : count - 1)];
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const float t = (i0 + k < count) ? plane_candidate(pl[k], o, d, cur, bt) : -1.0f;
-                if (t > 0.0f) {
-                    const int tri = sc.refs[first + i0 + k];
-                    const f4 pa = sc.tri_pos[3 * (size_t)tri], pb = sc.tri_pos[3 * (size_t)tri + 1],
-                             pc = sc.tri_pos[3 * (size_t)tri + 2];
-                    if (inside_triangle(pl[k], mk3(pa.x, pa.y, pa.z), mk3(pb.x, pb.y, pb.z), mk3(pc.x, pc.y, pc.z), o, d, t)) {
-                        bt = t;
-                        bi = tri;
-                    }
-                }
-            }
-        }
-        if (bt > 0.0f) {
+        const KdNode leaf = descend_to_leaf<Stack, COUNT>(sc, o, d, cur, node, sp, stk, ctr);
+        float bt;
+        int bi;
+        leaf_closest<COUNT>(sc, leaf, o, d, cur, bt, bi, ctr);
+        if (bt > 0.0f) {  // mesh.cuh:300: the first leaf with an accepted hit ends the search (Q8)
             best_t = bt;
             best_tri = bi;
             return;

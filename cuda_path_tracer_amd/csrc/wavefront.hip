@@ -78,7 +78,8 @@ struct WfBuffers {
 constexpr int kCntCam = 0;      // + i  (camera queue feeding vertex i), i <= 16
 constexpr int kCntShadow = 20;  // + i
 constexpr int kCntLight = 40;   // + i
-constexpr int kCntTotal = 64;
+constexpr int kCntWork = 64;    // + launch index within the pass: ray cursor of each persistent extend launch
+constexpr int kCntTotal = 128;
 
 __global__ __launch_bounds__(kBlock) void k_raygen(DScene sc, PassParams pp, WfBuffers b) {
     const int pid = blockIdx.x * kBlock + threadIdx.x;
@@ -450,19 +451,17 @@ int wavefront_render(const HostScene &hs, DeviceCtx &dc, const mipt_render_confi
     hipEvent_t ev_begin = dc.events.next(), ev_end = dc.events.next();
     WF_TRY(hipEventRecord(ev_begin, sm));
 
+    int n_launch = 0;
     auto extend = [&](const f4 *ro, const f4 *rd, const int *queue, const int *count, HitRec *hits, size_t n_max) {
         hipEvent_t a = dc.events.next(), e = dc.events.next();
         (void)hipEventRecord(a, sm);
-        if (count_mode)
-            hipLaunchKernelGGL(k_extend<true>, dim3(extend_grid(dc, (int64_t)n_max)), dim3(kExtendBlock), 0, sm, dc.view, ro,
-                               rd, queue, count, 0, hits, dc.counters.as<unsigned long long>());
-        else
-            hipLaunchKernelGGL(k_extend<false>, dim3(extend_grid(dc, (int64_t)n_max)), dim3(kExtendBlock), 0, sm, dc.view, ro,
-                               rd, queue, count, 0, hits, (unsigned long long *)nullptr);
+        launch_extend(dc, count_mode, ro, rd, queue, count, 0, (int64_t)n_max, hits, &b.counts[kCntWork + (n_launch++)],
+                      dc.counters.as<unsigned long long>());
         (void)hipEventRecord(e, sm);
         ext_ev.emplace_back(a, e);
     };
     const int path_grid = (int)std::min<size_t>((P + kBlock - 1) / kBlock, (size_t)dc.num_cus * 16);
+    static_assert(3 * kMaxPathDepth <= kCntTotal - kCntWork, "work cursor table too small");
 
     PassParams pp;
     pp.W = cfg.width; pp.H = cfg.height; pp.npix = npix; pp.spp = cfg.spp; pp.sample_stride = stride;
@@ -473,6 +472,7 @@ int wavefront_render(const HostScene &hs, DeviceCtx &dc, const mipt_render_confi
         const size_t np = (size_t)pp.n_slots * npix;
         const unsigned full_grid = (unsigned)((np + kBlock - 1) / kBlock);
         WF_TRY(hipMemsetAsync(b.counts, 0, kCntTotal * 4, sm));
+        n_launch = 0;
         hipLaunchKernelGGL(k_raygen, dim3(full_grid), dim3(kBlock), 0, sm, dc.view, pp, b);
         if (Dl > 0) {
             hipLaunchKernelGGL(k_lightgen, dim3(full_grid), dim3(kBlock), 0, sm, dc.view, pp, b);
