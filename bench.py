@@ -81,6 +81,7 @@ def closest_hit_bench(torch, G, Scene, FLAG_COUNTERS, n_rays, with_cpu):
             "Mrays_per_s_incl_ray_setup": round(n_rays / float(np.median(ms_all)) / 1e3, 1),
             "ms_extend": round(ms, 3),
             "per_ray": {k: round(v, 2) for k, v in means.items()}, "hit_frac": round(hit_frac, 4),
+            "culled_candidate_frac": round(sc["ctr_culled"] / max(1, sc["ctr_tris"]), 4),
             "bytes_per_ray": round(bpr, 1),
             "roofline": {"bound": "hbm", "achieved": round(bpr * n_rays / (ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(bpr * n_rays / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": None},

@@ -24,7 +24,7 @@ class Stats(C.Structure):
         ("samples", C.c_int64), ("extend_launches", C.c_int64),
         ("ms_total", C.c_double), ("ms_extend", C.c_double), ("ms_other", C.c_double),
         ("ctr_nodes", C.c_int64), ("ctr_pops", C.c_int64), ("ctr_refs", C.c_int64), ("ctr_tris", C.c_int64),
-        ("ctr_hits", C.c_int64),
+        ("ctr_hits", C.c_int64), ("ctr_culled", C.c_int64),
     ]
 
     def as_dict(self):

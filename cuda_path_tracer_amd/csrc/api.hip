@@ -58,7 +58,7 @@ void fill_counters(DeviceCtx &dc, mipt_stats *st) {
     unsigned long long c[8] = {0};
     (void)hipMemcpy(c, dc.counters.p, sizeof(c), hipMemcpyDeviceToHost);
     st->ctr_nodes = (int64_t)c[0]; st->ctr_pops = (int64_t)c[1]; st->ctr_refs = (int64_t)c[2];
-    st->ctr_tris = (int64_t)c[3]; st->ctr_hits = (int64_t)c[4];
+    st->ctr_tris = (int64_t)c[3]; st->ctr_hits = (int64_t)c[4]; st->ctr_culled = (int64_t)c[5];
 }
 }  // namespace
 

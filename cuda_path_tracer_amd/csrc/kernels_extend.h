@@ -32,13 +32,14 @@ __device__ __forceinline__ unsigned int wave_sum(unsigned int v) {
 
 __device__ __forceinline__ void flush_counters(const TravCounters &tc, unsigned int hit_tris, unsigned long long *ctr) {
     const unsigned int a = wave_sum(tc.nodes), b = wave_sum(tc.pops), c = wave_sum(tc.refs), d = wave_sum(tc.tris),
-                       e = wave_sum(hit_tris);
+                       e = wave_sum(hit_tris), f = wave_sum(tc.culled);
     if ((threadIdx.x & 63) == 0) {
         atomicAdd(&ctr[0], (unsigned long long)a);
         atomicAdd(&ctr[1], (unsigned long long)b);
         atomicAdd(&ctr[2], (unsigned long long)c);
         atomicAdd(&ctr[3], (unsigned long long)d);
         atomicAdd(&ctr[4], (unsigned long long)e);
+        atomicAdd(&ctr[5], (unsigned long long)f);
     }
 }
 
@@ -54,7 +55,7 @@ __global__ __launch_bounds__(kExtendBlock) void k_extend(DScene sc, const f4 *__
     LdsStack stk{stack_mem + threadIdx.x};
     const int n = count_ptr ? *count_ptr : n_fixed;
     const int lane = (int)(threadIdx.x & 63u);
-    TravCounters tc = {0u, 0u, 0u, 0u};
+    TravCounters tc = {0u, 0u, 0u, 0u, 0u};
     unsigned int hit_tris = 0;
 
     bool has_ray = false, exhausted = false;
@@ -132,7 +133,7 @@ __global__ __launch_bounds__(kExtendBlock) void k_extend(DScene sc, const f4 *__
         const KdNode leaf = descend_to_leaf<LdsStack, COUNT>(sc, o, d, cur, node, sp, stk, tc);
         float bt;
         int bi;
-        leaf_closest<COUNT>(sc, leaf, o, d, cur, bt, bi, tc);
+        leaf_closest<COUNT>(sc, node, leaf, o, d, cur, bt, bi, tc);
         if (bt > 0.0f) {  // mesh.cuh:300 first accepting leaf ends this mesh; kernel.cu:149 merge (strict '<')
             if (best < 0.0f || bt < best) { best = bt; prim = bi; }
             m++;
@@ -161,7 +162,7 @@ __global__ __launch_bounds__(kExtendBlock) void k_extend_simple(DScene sc, const
     __shared__ int stack_mem[kStackDepth * kExtendBlock];
     LdsStack stk{stack_mem + threadIdx.x};
     const int n = count_ptr ? *count_ptr : n_fixed;
-    TravCounters tc = {0u, 0u, 0u, 0u};
+    TravCounters tc = {0u, 0u, 0u, 0u, 0u};
     unsigned int hit_tris = 0;
     for (int i = blockIdx.x * kExtendBlock + threadIdx.x; i < n; i += gridDim.x * kExtendBlock) {
         const int slot = queue ? queue[i] : i;

@@ -319,6 +319,7 @@ bool HostScene::pack(int n_threads, std::string &err) {
     auto section = [&](size_t bytes) { size_t o = off; off = align_up(off + std::max<size_t>(bytes, 16), 256); return o; };
     L.nodes = section((size_t)total_nodes * sizeof(KdNode));
     L.boxes = section((size_t)total_nodes * 32);
+    L.tight = section((size_t)total_nodes * 32);
     L.refs = section((size_t)total_refs * 4);
     L.leaf_planes = section((size_t)total_refs * 16);
     L.tri_pos = section((size_t)total_tris * 48);
@@ -344,6 +345,30 @@ bool HostScene::pack(int n_threads, std::string &err) {
             nodes[i] = k;
         }
         memcpy(A + L.boxes + (size_t)hm.node_base * 32, t.boxes.data(), (size_t)hm.n_nodes * 32);
+        // per-leaf cull box: (AABB of the leaf's triangles) intersected with the leaf box.  An accepted hit point lies
+        // on one of those triangles AND inside the leaf box (mesh.cuh:293-296), so a ray that misses this box -- tested
+        // conservatively, see leaf_culled() -- cannot find anything in the leaf and its candidates are skipped.
+        float *tight = reinterpret_cast<float *>(A + L.tight) + (size_t)hm.node_base * 8;
+        for (int64_t i = 0; i < hm.n_nodes; i++) {
+            const KdNode k = t.nodes[(size_t)i];
+            float *tb = tight + 8 * i;
+            const float *nb = t.boxes.data() + 8 * (size_t)i;
+            for (int a = 0; a < 8; a++) tb[a] = nb[a];
+            if ((k.b >> 30) != 3u) continue;
+            const int cnt = (int)(k.b & kIdxMask);
+            float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+            for (int r = 0; r < cnt; r++) {
+                const float *v = hm.pos.data() + (size_t)t.refs[(size_t)k.a + r] * 9;
+                for (int c = 0; c < 9; c++) {
+                    lo[c % 3] = std::min(lo[c % 3], v[c]);
+                    hi[c % 3] = std::max(hi[c % 3], v[c]);
+                }
+            }
+            for (int a = 0; a < 3; a++) {  // empty leaf: lo=+inf, hi=-inf -> every ray is culled (nothing to find)
+                tb[2 * a] = std::max(nb[2 * a], lo[a]);
+                tb[2 * a + 1] = std::min(nb[2 * a + 1], hi[a]);
+            }
+        }
         int32_t *refs = reinterpret_cast<int32_t *>(A + L.refs) + hm.ref_base;
         for (int64_t i = 0; i < hm.n_refs; i++) refs[i] = t.refs[(size_t)i] + (int32_t)hm.tri_base;
         // leaf-ordered plane records: N = cross(b-a, c-a), dd = -dot(N, a) exactly as Triangle::intersect
@@ -409,6 +434,7 @@ DScene HostScene::view(const void *base_v) const {
     memset(&d, 0, sizeof(d));
     d.nodes = reinterpret_cast<const KdNode *>(base + layout.nodes);
     d.boxes = reinterpret_cast<const f4 *>(base + layout.boxes);
+    d.tight = reinterpret_cast<const f4 *>(base + layout.tight);
     d.refs = reinterpret_cast<const int32_t *>(base + layout.refs);
     d.leaf_planes = reinterpret_cast<const f4 *>(base + layout.leaf_planes);
     d.tri_pos = reinterpret_cast<const f4 *>(base + layout.tri_pos);

@@ -49,6 +49,7 @@ struct f4 {
 struct DScene {
     const KdNode *nodes;
     const f4 *boxes;
+    const f4 *tight;        // per node, same layout as boxes: leaf cull box (triangle AABB within the leaf box)
     const int32_t *refs;
     const f4 *leaf_planes;  // per leaf reference: (N.xyz, -dot(N,a)) of that triangle, in leaf order
     const f4 *tri_pos;

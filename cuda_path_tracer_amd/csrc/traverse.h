@@ -22,7 +22,8 @@
 namespace mipt {
 
 struct TravCounters {
-    unsigned int nodes, pops, refs, tris;
+    unsigned int nodes, pops, refs, tris;  // units of the reference's traversal
+    unsigned int culled;                   // candidates of those that the leaf cull skipped
 };
 
 PT_HD float as_f32(uint32_t u) {
@@ -150,12 +151,45 @@ PT_HD KdNode descend_to_leaf(const DScene &sc, f3 o, f3 d, SlabBox &cur, int &no
 // Leaf loop of Mesh::intersect (mesh.cuh:290-299).  The 16-byte plane records of a leaf are contiguous: four
 // are fetched ahead of use (indices clamped, so every load is in bounds) and evaluated in leaf order -- the
 // sequential "t < best" rule keeps the earliest of equal hits.
+//
+// Leaf cull (no counterpart in the reference; it changes no result): an accepted hit point lies on a triangle of
+// the leaf and inside the leaf box, hence inside sc.tight[node] = AABB(leaf triangles) ∩ leaf box.  The ray is
+// tested against that box grown by a margin of 2^-12 x (largest coordinate magnitude in play) -- thousands of ulps,
+// far beyond the rounding of P = o + d*t, of the fp32 edge tests and of the 1e-5 box slack -- with the standard
+// interval test.  A ray that misses the grown box cannot produce an accepted candidate, so the loop is skipped.
+PT_HD bool leaf_culled(const DScene &sc, int node, f3 o, f3 d) {
+    const f4 b0 = sc.tight[2 * (size_t)node], b1 = sc.tight[2 * (size_t)node + 1];
+    const float lo[3] = {b0.x, b0.z, b1.x}, hi[3] = {b0.y, b0.w, b1.y};
+    const float oo[3] = {o.x, o.y, o.z}, dd[3] = {d.x, d.y, d.z};
+    float tn = 0.0f, tf = __builtin_inff();
+    bool out = false;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const float mg = 2.44140625e-4f * fmaxf(fmaxf(fabsf(lo[k]), fabsf(hi[k])), fmaxf(fabsf(oo[k]), 1.0f));
+        const float l = lo[k] - mg, h = hi[k] + mg;
+        if (fabsf(dd[k]) < 1e-30f) {
+            out |= (oo[k] < l) | (oo[k] > h);
+        } else {
+            const float t0 = (l - oo[k]) / dd[k], t1 = (h - oo[k]) / dd[k];
+            tn = fmaxf(tn, fminf(t0, t1));
+            tf = fminf(tf, fmaxf(t0, t1));
+        }
+    }
+    // widen the interval itself by a relative margin as well (rounding of the divisions)
+    return out | (tn > tf + 2.44140625e-4f * (fabsf(tf) + 1.0f)) | !(lo[0] <= hi[0]);
+}
+
 template <bool COUNT>
-PT_HD void leaf_closest(const DScene &sc, KdNode nd, f3 o, f3 d, const SlabBox &cur, float &bt, int &bi, TravCounters &ctr) {
+PT_HD void leaf_closest(const DScene &sc, int node, KdNode nd, f3 o, f3 d, const SlabBox &cur, float &bt, int &bi,
+                        TravCounters &ctr) {
     const int first = (int)nd.a, count = (int)(nd.b & kIdxMask);
     bt = -1.0f;
     bi = -1;
     if (COUNT) { ctr.refs += count; ctr.tris += count; }
+    if (leaf_culled(sc, node, o, d)) {
+        if (COUNT) ctr.culled += count;
+        return;
+    }
     for (int i0 = 0; i0 < count; i0 += 4) {
         f4 pl[4];
 #pragma unroll
@@ -191,7 +225,7 @@ PT_HD void mesh_closest(const DScene &sc, int root, f3 o, f3 d, Stack &stk, floa
         const KdNode leaf = descend_to_leaf<Stack, COUNT>(sc, o, d, cur, node, sp, stk, ctr);
         float bt;
         int bi;
-        leaf_closest<COUNT>(sc, leaf, o, d, cur, bt, bi, ctr);
+        leaf_closest<COUNT>(sc, node, leaf, o, d, cur, bt, bi, ctr);
         if (bt > 0.0f) {  // mesh.cuh:300: the first leaf with an accepted hit ends the search (Q8)
             best_t = bt;
             best_tri = bi;

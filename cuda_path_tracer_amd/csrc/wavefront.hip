@@ -518,7 +518,7 @@ int wavefront_render(const HostScene &hs, DeviceCtx &dc, const mipt_render_confi
             unsigned long long c[8] = {0};
             WF_TRY(hipMemcpy(c, dc.counters.p, sizeof(c), hipMemcpyDeviceToHost));
             st->ctr_nodes = (int64_t)c[0]; st->ctr_pops = (int64_t)c[1]; st->ctr_refs = (int64_t)c[2];
-            st->ctr_tris = (int64_t)c[3]; st->ctr_hits = (int64_t)c[4];
+            st->ctr_tris = (int64_t)c[3]; st->ctr_hits = (int64_t)c[4]; st->ctr_culled = (int64_t)c[5];
         }
     }
     return 0;

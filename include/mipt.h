@@ -45,6 +45,7 @@ typedef struct mipt_stats {
     double ms_other;         /* raygen/shade/connect/resolve/accumulate                          */
     /* traversal counters, filled only when MIPT_FLAG_COUNTERS is requested (slower kernel):   */
     int64_t ctr_nodes, ctr_pops, ctr_refs, ctr_tris, ctr_hits;
+    int64_t ctr_culled;      /* of ctr_tris: candidates skipped by the per-leaf cull box (never changes a result) */
 } mipt_stats;
 
 enum { MIPT_FLAG_COUNTERS = 1 };
