@@ -16,7 +16,8 @@
 namespace mipt {
 
 constexpr int kExtendBlock = 256;
-constexpr int kRefillLanes = 12;  // refill a wave once this many lanes are idle (or all of them)
+constexpr int kRefillLanes = 12;     // refill a wave once this many lanes are idle (or all of them)
+constexpr int kLeafBatchLanes = 20;  // scan leaves once this many lanes wait at one (or few lanes still traverse)
 
 struct LdsStack {
     int *col;  // &stack[threadIdx.x]
@@ -60,6 +61,8 @@ __global__ __launch_bounds__(kExtendBlock) void k_extend(DScene sc, const f4 *__
 
     bool has_ray = false, exhausted = false;
     bool start_mesh = false;  // lane must open mesh `m` (or finish the ray when m == n_meshes)
+    bool pending = false;     // lane sits at an un-culled leaf (leaf_first/leaf_count) waiting for a batched scan
+    int leaf_first = 0, leaf_count = 0;
     int slot = 0, m = 0, node = 0, sp = 0, prim = -1;
     float best = -1.0f;
     f3 o = mk3(0.f, 0.f, 0.f), d = mk3(0.f, 0.f, 1.f);
@@ -97,7 +100,34 @@ __global__ __launch_bounds__(kExtendBlock) void k_extend(DScene sc, const f4 *__
             if (exhausted) break;
             continue;
         }
-        if (!has_ray) continue;
+        // ---- postponed leaf scans: run the candidate loop only when enough lanes wait for one -------------------
+        // (about 9 of 10 leaf visits are culled; scanning the rest one by one would run the loop at ~10% lane use)
+        {
+            const int n_pend = __popcll(__ballot(pending));
+            const int n_trav = __popcll(__ballot(has_ray && !pending));
+            if (n_pend >= kLeafBatchLanes || (n_pend > 0 && n_trav < kLeafBatchLanes)) {
+                if (pending) {
+                    float bt;
+                    int bi;
+                    leaf_scan(sc, leaf_first, leaf_count, o, d, cur, bt, bi);
+                    pending = false;
+                    if (bt > 0.0f) {  // mesh.cuh:300 first accepting leaf ends this mesh; kernel.cu:149 merge (strict '<')
+                        if (best < 0.0f || bt < best) { best = bt; prim = bi; }
+                        m++;
+                        start_mesh = true;
+                    } else if (sp == 0 || sp > kStackDepth) {  // stack empty (or, unreachable, overflowed): mesh missed
+                        m++;
+                        start_mesh = true;
+                    } else {
+                        sp--;
+                        node = stk.pop(sp);
+                        load_slab(sc, node, o, d, cur);
+                        if (COUNT) { tc.pops++; tc.nodes++; }
+                    }
+                }
+            }
+        }
+        if (!has_ray || pending) continue;
 
         // ---- one step of the lane's state machine --------------------------------------------------------
         if (start_mesh) {
@@ -131,21 +161,22 @@ __global__ __launch_bounds__(kExtendBlock) void k_extend(DScene sc, const f4 *__
             if (COUNT) { tc.pops++; tc.nodes++; }
         }
         const KdNode leaf = descend_to_leaf<LdsStack, COUNT>(sc, o, d, cur, node, sp, stk, tc);
-        float bt;
-        int bi;
-        leaf_closest<COUNT>(sc, node, leaf, o, d, cur, bt, bi, tc);
-        if (bt > 0.0f) {  // mesh.cuh:300 first accepting leaf ends this mesh; kernel.cu:149 merge (strict '<')
-            if (best < 0.0f || bt < best) { best = bt; prim = bi; }
-            m++;
-            start_mesh = true;
-        } else if (sp == 0 || sp > kStackDepth) {  // stack empty (or, unreachable, overflowed): mesh missed
-            m++;
-            start_mesh = true;
+        leaf_first = (int)leaf.a;
+        leaf_count = (int)(leaf.b & kIdxMask);
+        if (COUNT) { tc.refs += leaf_count; tc.tris += leaf_count; }
+        if (!leaf_culled(sc, node, o, d)) {
+            pending = true;  // scanned later, together with other lanes' leaves
         } else {
-            sp--;
-            node = stk.pop(sp);
-            load_slab(sc, node, o, d, cur);
-            if (COUNT) { tc.pops++; tc.nodes++; }
+            if (COUNT) tc.culled += leaf_count;
+            if (sp == 0 || sp > kStackDepth) {  // nothing found in this mesh
+                m++;
+                start_mesh = true;
+            } else {
+                sp--;
+                node = stk.pop(sp);
+                load_slab(sc, node, o, d, cur);
+                if (COUNT) { tc.pops++; tc.nodes++; }
+            }
         }
     }
     if (COUNT) flush_counters(tc, hit_tris, ctr);

@@ -179,10 +179,12 @@ PT_HD bool leaf_culled(const DScene &sc, int node, f3 o, f3 d) {
     return out | (tn > tf + 2.44140625e-4f * (fabsf(tf) + 1.0f)) | !(lo[0] <= hi[0]);
 }
 
+PT_HD void leaf_scan(const DScene &sc, int first, int count, f3 o, f3 d, const SlabBox &cur, float &bt, int &bi);
+
 template <bool COUNT>
 PT_HD void leaf_closest(const DScene &sc, int node, KdNode nd, f3 o, f3 d, const SlabBox &cur, float &bt, int &bi,
                         TravCounters &ctr) {
-    const int first = (int)nd.a, count = (int)(nd.b & kIdxMask);
+    const int count = (int)(nd.b & kIdxMask);
     bt = -1.0f;
     bi = -1;
     if (COUNT) { ctr.refs += count; ctr.tris += count; }
@@ -190,6 +192,13 @@ PT_HD void leaf_closest(const DScene &sc, int node, KdNode nd, f3 o, f3 d, const
         if (COUNT) ctr.culled += count;
         return;
     }
+    leaf_scan(sc, (int)nd.a, count, o, d, cur, bt, bi);
+}
+
+// The candidate loop proper: `count` plane records starting at reference `first`, leaf box in `cur`.
+PT_HD void leaf_scan(const DScene &sc, int first, int count, f3 o, f3 d, const SlabBox &cur, float &bt, int &bi) {
+    bt = -1.0f;
+    bi = -1;
     for (int i0 = 0; i0 < count; i0 += 4) {
         f4 pl[4];
 #pragma unroll
