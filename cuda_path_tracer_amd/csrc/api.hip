@@ -213,6 +213,7 @@ int mipt_scene_commit(mipt_scene *s, const int *device_ids, int n_devices) {
         dc.extend_blocks_per_cu = query_extend_blocks_per_cu();
         const char *ev = getenv("MIPT_EXTEND");
         dc.extend_simple = ev && std::string(ev) == "simple";
+        if (const char *tv = getenv("MIPT_TUNE")) sscanf(tv, "%d,%d,%d", &dc.tune.refill_lanes, &dc.tune.leaf_batch_lanes, &dc.tune.step_cap);
         dc.view = s->host.view(dc.arena);
         s->devs.push_back(dc);
     }
@@ -398,7 +399,7 @@ int mipt_kd_export(mipt_scene *s, int mesh, float *boxes, int32_t *axis, int32_t
         }
         if (axis) axis[i] = leaf ? -1 : (int32_t)(k.b >> 30);
         if (left) left[i] = leaf ? -1 : (int32_t)((k.b & kIdxMask) - (uint32_t)m.node_base);
-        if (right) right[i] = leaf ? -1 : (int32_t)(i + 1);
+        if (right) right[i] = leaf ? -1 : (int32_t)((k.b & kIdxMask) - (uint32_t)m.node_base + 1u);
         if (first) first[i] = leaf ? (int32_t)(k.a - (uint32_t)m.ref_base) : 0;
         if (count) count[i] = leaf ? (int32_t)(k.b & kIdxMask) : 0;
     }

@@ -52,6 +52,13 @@ struct EventPool {
     }
 };
 
+// Scheduling knobs of the persistent extend kernel (wave-uniform kernel arguments; MIPT_TUNE="refill,batch,cap").
+struct ExtendTuning {
+    int refill_lanes = 12;      // refill a wave once this many lanes are idle (or all of them)
+    int leaf_batch_lanes = 24;  // scan leaves once this many lanes wait at one (or fewer lanes than this still traverse)
+    int step_cap = 4;           // node steps per lane per round before lanes re-converge (measured best: 4)
+};
+
 struct DeviceCtx {
     int device = -1;
     hipStream_t stream = nullptr;
@@ -59,6 +66,7 @@ struct DeviceCtx {
     DScene view;
     int num_cus = 256;
     int extend_blocks_per_cu = 4;  // resident blocks of the persistent extend kernel
+    ExtendTuning tune;
     bool extend_simple = false;    // MIPT_EXTEND=simple: grid-stride reference kernel (A/B timing)
     // closest-hit work buffers
     DevBuf ray_o, ray_d, hits, io_a, io_b, io_c, io_d, counters;

@@ -146,11 +146,12 @@ struct Builder {
     }
 };
 
-void flatten(const TNode *nd, KdTree &out, int depth) {
-    const size_t idx = out.nodes.size();
-    out.nodes.push_back(KdNode{0, 0});
+// Flat layout: the two children of an interior node are ADJACENT (left at c, right at c + 1, c even), so one
+// aligned 16-byte load issued at the start of a traversal step brings in both child nodes while the step's
+// arithmetic runs.  Slot 0 is the root, slot 1 is padding that keeps every pair 16-byte aligned.
+void flatten(const TNode *nd, size_t idx, KdTree &out, int depth) {
     const float b[8] = {nd->lo[0], nd->hi[0], nd->lo[1], nd->hi[1], nd->lo[2], nd->hi[2], 0.f, 0.f};
-    out.boxes.insert(out.boxes.end(), b, b + 8);
+    std::copy(b, b + 8, out.boxes.begin() + 8 * idx);
     out.max_depth = std::max(out.max_depth, depth);
     if (nd->degenerate) out.degenerate_nodes++;
     if (!nd->left) {
@@ -163,15 +164,17 @@ void flatten(const TNode *nd, KdTree &out, int depth) {
         out.max_leaf = std::max<int64_t>(out.max_leaf, (int64_t)nd->tris.size());
         return;
     }
-    flatten(nd->right.get(), out, depth + 1);  // right child sits at idx + 1
-    const size_t left_idx = out.nodes.size();
-    flatten(nd->left.get(), out, depth + 1);
+    const size_t pair = out.nodes.size();
+    out.nodes.resize(pair + 2, KdNode{0, kLeafTag});
+    out.boxes.resize(8 * (pair + 2), 0.f);
     KdNode k;
     union { float f; uint32_t u; } cv;
     cv.f = nd->split;
     k.a = cv.u;
-    k.b = ((uint32_t)nd->axis << 30) | (uint32_t)left_idx;
+    k.b = ((uint32_t)nd->axis << 30) | (uint32_t)pair;
     out.nodes[idx] = k;
+    flatten(nd->left.get(), pair, out, depth + 1);
+    flatten(nd->right.get(), pair + 1, out, depth + 1);
 }
 
 }  // namespace
@@ -194,8 +197,9 @@ void build_kd_tree(const float *pos, int64_t n_tris, KdTree &out, int n_threads)
     b.pos = pos;
     b.spare_threads.store(std::max(0, n_threads - 1));
     b.build(root.get(), std::move(all), 0);
-    out.nodes.reserve(1024);
-    flatten(root.get(), out, 0);
+    out.nodes.assign(2, KdNode{0, kLeafTag});  // root + one padding slot (an empty leaf nobody references)
+    out.boxes.assign(16, 0.f);
+    flatten(root.get(), 0, out, 0);
 }
 
 }  // namespace mipt

@@ -7,7 +7,7 @@
 namespace mipt {
 
 struct KdTree {
-    std::vector<KdNode> nodes;    // mesh-local indices (left child in node.b, right = idx+1), local ref offsets
+    std::vector<KdNode> nodes;    // mesh-local indices (node.b = index of the child pair: left, right = left+1), local ref offsets; slot 1 is padding
     std::vector<float> boxes;     // 8 floats per node: minX,maxX,minY,maxY,minZ,maxZ,0,0
     std::vector<int32_t> refs;    // mesh-local triangle ids
     int64_t degenerate_nodes = 0; // nodes that fell back to a leaf (no split candidate / zero width)

@@ -16,8 +16,6 @@
 namespace mipt {
 
 constexpr int kExtendBlock = 256;
-constexpr int kRefillLanes = 12;     // refill a wave once this many lanes are idle (or all of them)
-constexpr int kLeafBatchLanes = 20;  // scan leaves once this many lanes wait at one (or few lanes still traverse)
 
 struct LdsStack {
     int *col;  // &stack[threadIdx.x]
@@ -51,7 +49,7 @@ __global__ __launch_bounds__(kExtendBlock) void k_extend(DScene sc, const f4 *__
                                                          const f4 *__restrict__ ray_d, const int *__restrict__ queue,
                                                          const int *__restrict__ count_ptr, int n_fixed,
                                                          HitRec *__restrict__ hits, int *__restrict__ work,
-                                                         unsigned long long *ctr) {
+                                                         unsigned long long *ctr, ExtendTuning tune) {
     __shared__ int stack_mem[kStackDepth * kExtendBlock];
     LdsStack stk{stack_mem + threadIdx.x};
     const int n = count_ptr ? *count_ptr : n_fixed;
@@ -64,6 +62,7 @@ __global__ __launch_bounds__(kExtendBlock) void k_extend(DScene sc, const f4 *__
     bool pending = false;     // lane sits at an un-culled leaf (leaf_first/leaf_count) waiting for a batched scan
     int leaf_first = 0, leaf_count = 0;
     int slot = 0, m = 0, node = 0, sp = 0, prim = -1;
+    KdNode nd = {0u, kLeafTag};  // the 8 bytes of `node`
     float best = -1.0f;
     f3 o = mk3(0.f, 0.f, 0.f), d = mk3(0.f, 0.f, 1.f);
     SlabBox cur;
@@ -75,7 +74,7 @@ __global__ __launch_bounds__(kExtendBlock) void k_extend(DScene sc, const f4 *__
         const unsigned long long idle = __ballot(!has_ray);
         if (idle != 0ull && !exhausted) {
             const int n_idle = __popcll(idle);
-            if (n_idle >= kRefillLanes || n_idle == 64) {
+            if (n_idle >= tune.refill_lanes || n_idle == 64) {
                 const int leader = __ffsll((long long)idle) - 1;
                 int base = 0;
                 if (lane == leader) base = atomicAdd(work, n_idle);
@@ -105,7 +104,7 @@ __global__ __launch_bounds__(kExtendBlock) void k_extend(DScene sc, const f4 *__
         {
             const int n_pend = __popcll(__ballot(pending));
             const int n_trav = __popcll(__ballot(has_ray && !pending));
-            if (n_pend >= kLeafBatchLanes || (n_pend > 0 && n_trav < kLeafBatchLanes)) {
+            if (n_pend >= tune.leaf_batch_lanes || (n_pend > 0 && n_trav < tune.leaf_batch_lanes)) {
                 if (pending) {
                     float bt;
                     int bi;
@@ -121,6 +120,7 @@ __global__ __launch_bounds__(kExtendBlock) void k_extend(DScene sc, const f4 *__
                     } else {
                         sp--;
                         node = stk.pop(sp);
+                        nd = sc.nodes[node];
                         load_slab(sc, node, o, d, cur);
                         if (COUNT) { tc.pops++; tc.nodes++; }
                     }
@@ -151,6 +151,7 @@ __global__ __launch_bounds__(kExtendBlock) void k_extend(DScene sc, const f4 *__
                 continue;
             }
             node = sc.meshes[m].root;
+            nd = sc.nodes[node];
             load_slab(sc, node, o, d, cur);
             if (!(slab_hit(cur, o, d) > 0.0f)) {  // mesh.cuh:254: the ray misses the mesh's root box
                 m++;
@@ -160,7 +161,9 @@ __global__ __launch_bounds__(kExtendBlock) void k_extend(DScene sc, const f4 *__
             start_mesh = false;
             if (COUNT) { tc.pops++; tc.nodes++; }
         }
-        const KdNode leaf = descend_to_leaf<LdsStack, COUNT>(sc, o, d, cur, node, sp, stk, tc);
+        descend_to_leaf<LdsStack, COUNT>(sc, o, d, cur, node, nd, sp, stk, tc, tune.step_cap);
+        if ((nd.b >> 30) != 3u) continue;  // out of steps for this round: keep walking next round
+        const KdNode leaf = nd;
         leaf_first = (int)leaf.a;
         leaf_count = (int)(leaf.b & kIdxMask);
         if (COUNT) { tc.refs += leaf_count; tc.tris += leaf_count; }
@@ -174,6 +177,7 @@ __global__ __launch_bounds__(kExtendBlock) void k_extend(DScene sc, const f4 *__
             } else {
                 sp--;
                 node = stk.pop(sp);
+                nd = sc.nodes[node];
                 load_slab(sc, node, o, d, cur);
                 if (COUNT) { tc.pops++; tc.nodes++; }
             }
@@ -248,10 +252,10 @@ inline void launch_extend(const DeviceCtx &dc, bool count, const f4 *ro, const f
     const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(want, (int64_t)dc.num_cus * dc.extend_blocks_per_cu));
     if (count)
         hipLaunchKernelGGL(k_extend<true>, dim3(grid), dim3(kExtendBlock), 0, dc.stream, dc.view, ro, rd, queue, count_ptr,
-                           n_fixed, hits, work, ctr);
+                           n_fixed, hits, work, ctr, dc.tune);
     else
         hipLaunchKernelGGL(k_extend<false>, dim3(grid), dim3(kExtendBlock), 0, dc.stream, dc.view, ro, rd, queue, count_ptr,
-                           n_fixed, hits, work, ctr);
+                           n_fixed, hits, work, ctr, dc.tune);
 }
 
 // Resident 256-thread blocks per CU of the persistent kernel (occupancy API, capped like the hardware admits).

@@ -5,7 +5,7 @@
 // leaf made through copyToDevice (copyToDevice.h:8-55).  The whole scene lives in ONE device arena:
 //
 //   nodes    uint2[n_nodes]     8-byte kd node.  interior: x = bits(split plane), y = axis<<30 | left child
-//                               (right child = own index + 1); leaf: x = first ref, y = 3<<30 | count
+//                               (right child = left + 1, pair 16-byte aligned); leaf: x = first ref, y = 3<<30 | count
 //   boxes    float4[2*n_nodes]  (minX,maxX,minY,maxY) (minZ,maxZ,-,-): read for the root and on stack pops only
 //   refs     int32[n_refs]      leaf triangle index lists (global triangle ids, leaf order = input order)
 //   leaf_planes float4[n_refs]   plane record (N, -N.a) of each reference, contiguous per leaf: the leaf loop
@@ -32,6 +32,10 @@ constexpr uint32_t kIdxMask = (1u << 30) - 1;
 
 struct KdNode {
     uint32_t a, b;
+};
+
+struct alignas(16) KdNodePair {  // the two children of an interior node: left, right
+    KdNode l, r;
 };
 
 struct DMesh {

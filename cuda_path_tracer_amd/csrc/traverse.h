@@ -104,14 +104,18 @@ PT_HD bool inside_triangle(f4 pl, f3 a, f3 b, f3 c, f3 o, f3 d, float t) {
     return true;
 }
 
-// Inner loop of Mesh::intersect (mesh.cuh:265-288): walk from `node` down to a leaf, pushing the far child
-// when both children are hit (Q7).  `cur` (bounds + plane parameters of `node`) is updated in place.
+// Inner loop of Mesh::intersect (mesh.cuh:265-288): walk from `node` (whose 8 bytes are in `nd`) down towards a
+// leaf, pushing the far child when both children are hit (Q7).  `cur` (bounds + plane parameters of `node`)
+// is updated in place.  Both children sit in one aligned 16-byte pair; its load is issued first and is only
+// consumed after the step's slab arithmetic, which hides most of the node-fetch latency.
+// Stops at a leaf or after `max_steps` steps (then `nd` is still interior).
 template <class Stack, bool COUNT>
-PT_HD KdNode descend_to_leaf(const DScene &sc, f3 o, f3 d, SlabBox &cur, int &node, int &sp, Stack &stk, TravCounters &ctr) {
-    KdNode nd = sc.nodes[node];
-    while ((nd.b >> 30) != 3u) {
+PT_HD void descend_to_leaf(const DScene &sc, f3 o, f3 d, SlabBox &cur, int &node, KdNode &nd, int &sp, Stack &stk,
+                           TravCounters &ctr, int max_steps = 1 << 30) {
+    for (int step = 0; (nd.b >> 30) != 3u && step < max_steps; step++) {
         const uint32_t ax = nd.b >> 30;
-        const int left = (int)(nd.b & kIdxMask), right = node + 1;
+        const int left = (int)(nd.b & kIdxMask), right = left + 1;
+        const KdNodePair pair = *reinterpret_cast<const KdNodePair *>(sc.nodes + left);
         const float s = as_f32(nd.a);
         const float oa = ax == 0 ? o.x : (ax == 1 ? o.y : o.z);
         const float da = ax == 0 ? d.x : (ax == 1 ? d.y : d.z);
@@ -142,10 +146,10 @@ PT_HD KdNode descend_to_leaf(const DScene &sc, f3 o, f3 d, SlabBox &cur, int &no
             cur.thi[k] = go_right ? cur.thi[k] : lb.thi[k];
         }
         node = go_right ? right : left;
-        nd = sc.nodes[node];
+        nd.a = go_right ? pair.r.a : pair.l.a;
+        nd.b = go_right ? pair.r.b : pair.l.b;
         if (COUNT) ctr.nodes++;
     }
-    return nd;
 }
 
 // Leaf loop of Mesh::intersect (mesh.cuh:290-299).  The 16-byte plane records of a leaf are contiguous: four
@@ -230,8 +234,9 @@ PT_HD void mesh_closest(const DScene &sc, int root, f3 o, f3 d, Stack &stk, floa
     int node = root;
     int sp = 0;
     if (COUNT) { ctr.pops++; ctr.nodes++; }
+    KdNode leaf = sc.nodes[node];
     for (;;) {
-        const KdNode leaf = descend_to_leaf<Stack, COUNT>(sc, o, d, cur, node, sp, stk, ctr);
+        descend_to_leaf<Stack, COUNT>(sc, o, d, cur, node, leaf, sp, stk, ctr);
         float bt;
         int bi;
         leaf_closest<COUNT>(sc, node, leaf, o, d, cur, bt, bi, ctr);
@@ -244,6 +249,7 @@ PT_HD void mesh_closest(const DScene &sc, int root, f3 o, f3 d, Stack &stk, floa
         sp--;
         if (sp >= kStackDepth) return;  // unreachable for trees built by kd_build.cpp (depth <= 16)
         node = stk.pop(sp);
+        leaf = sc.nodes[node];
         load_slab(sc, node, o, d, cur);
         if (COUNT) { ctr.pops++; ctr.nodes++; }
     }
