@@ -45,7 +45,7 @@ __device__ __forceinline__ void flush_counters(const TravCounters &tc, unsigned 
 // rays: o/d as float4 (w unused), d already normalised by the Ray constructor rule (ray.cuh:10).
 // queue: optional indirection (slot ids); count_ptr: optional device-side ray count; work: zeroed counter.
 template <bool COUNT>
-__global__ __launch_bounds__(kExtendBlock) void k_extend(DScene sc, const f4 *__restrict__ ray_o,
+__global__ __launch_bounds__(kExtendBlock, 5) void k_extend(DScene sc, const f4 *__restrict__ ray_o,
                                                          const f4 *__restrict__ ray_d, const int *__restrict__ queue,
                                                          const int *__restrict__ count_ptr, int n_fixed,
                                                          HitRec *__restrict__ hits, int *__restrict__ work,
