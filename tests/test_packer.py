@@ -1,0 +1,133 @@
+"""CPU: the product's host side (kd builder, packer, OBJ reader, C-ABI surface) against the oracle -- no GPU needed
+(mipt_scene_commit with zero devices packs on the host only; no compute entry point is called here)."""
+import ctypes as C
+import os
+import re
+import sys
+
+import numpy as np
+import pytest
+
+from cuda_path_tracer_amd import _lib, generators as G
+from cuda_path_tracer_amd.scene import Scene, make_config
+from oracle.binding import OracleScene
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.setrecursionlimit(100000)
+
+
+def _walk(k, i, out):
+    if k["left"][i] < 0:
+        out.append((tuple(k["boxes"][i]), tuple(k["refs"][k["first"][i]:k["first"][i] + k["count"][i]])))
+    else:
+        out.append((tuple(k["boxes"][i]), int(k["axis"][i])))
+        _walk(k, k["right"][i], out)
+        _walk(k, k["left"][i], out)
+
+
+def _pair(desc):
+    s = desc.apply(Scene())
+    s.commit(devices=())
+    o = desc.apply(OracleScene())
+    o.commit()
+    return s, o
+
+
+@pytest.mark.parametrize("level", [2, 4, 6])
+def test_kd_tree_identical_to_oracle(level):
+    s, o = _pair(G.scene_icosphere_room(level))
+    a, b = s.kd_export(0), o.kd_export(0)
+    wa, wb = [], []
+    _walk(a, 0, wa)
+    _walk(b, 0, wb)
+    assert wa == wb                      # same boxes (bitwise), axes, leaf membership and leaf order
+    assert len(a["refs"]) == len(b["refs"])
+    # packed layout: children adjacent (right = left + 1) at even indices, padding slot 1 unused
+    inner = a["left"] >= 0
+    assert (a["right"][inner] == a["left"][inner] + 1).all() and (a["left"][inner] % 2 == 0).all()
+    assert len(a["axis"]) == len(b["axis"]) + 1
+
+
+def test_multi_mesh_and_obj_path(cube_obj):
+    s, o = _pair(G.scene_default(cube_obj))
+    assert s.mesh_count() == o.mesh_count() == 3
+    for m in range(3):
+        ps, ns = s.mesh_triangles(m)
+        po, no = o.mesh_triangles(m)
+        assert np.array_equal(ps, po) and np.array_equal(ns, no)   # readObjIntoMesh incl. y/z swap + SRT, bitwise
+        wa, wb = [], []
+        _walk(s.kd_export(m), 0, wa)
+        _walk(o.kd_export(m), 0, wb)
+        assert wa == wb
+    # mesh 2 is rotated by pi about y: the cube lands on x in [-3,-1]
+    p2, _ = s.mesh_triangles(2)
+    assert p2[..., 0].min() == pytest.approx(-3, abs=1e-4) and p2[..., 0].max() == pytest.approx(-1, abs=1e-4)
+    assert s.device_bytes() > 0 and s.build_seconds() >= 0
+
+
+def test_flat_mesh_degenerate_split_becomes_leaf():
+    # a planar, axis-aligned mesh has zero width on one axis: the reference divides 0/0 there (mesh.cu:76-78);
+    # both builders fall back to a leaf instead (documented deviation) and still agree with each other
+    n = 12
+    xs = np.linspace(0, 1, n + 1, dtype=np.float32)
+    tris = []
+    for i in range(n):
+        for j in range(n):
+            a, b, c, d = (xs[i], xs[j], 0), (xs[i + 1], xs[j], 0), (xs[i + 1], xs[j + 1], 0), (xs[i], xs[j + 1], 0)
+            tris += [(a, b, c), (a, c, d)]
+    pos = np.array(tris, np.float32)
+    nrm = np.tile(np.array([0, 0, 1], np.float32), (pos.shape[0], 3, 1))
+    desc = G.SceneDesc(materials=[((1, 1, 1), (0, 0, 0))], meshes=[("arrays", pos, nrm, 0)])
+    s, o = _pair(desc)
+    wa, wb = [], []
+    _walk(s.kd_export(0), 0, wa)
+    _walk(o.kd_export(0), 0, wb)
+    assert wa == wb
+
+
+def test_cabi_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "mipt.h")).read()
+    declared = set(re.findall(r"\b(mipt_[a-z0-9_]+)\s*\(", hdr))
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    lib = C.CDLL(_lib.LIB_PATH)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert b"gfx950" in _lib.load().mipt_version()
+
+
+def test_cabi_struct_sizes_match_header():
+    # mipt_render_config: 12 x int32; mipt_stats: 6 x int64 + 3 x double + 6 x int64
+    assert C.sizeof(_lib.RenderConfig) == 48 and C.sizeof(_lib.Stats) == 15 * 8
+
+
+def test_error_behaviour_without_device():
+    s = Scene()
+    with pytest.raises(_lib.MiptError, match="unknown material"):
+        s.add_plane((0, 0, 0), (0, 1, 0), 3)
+    m = s.add_material((0.5, 0.5, 0.5), (0, 0, 0))
+    with pytest.raises(_lib.MiptError, match="at least one triangle"):
+        s.add_mesh(np.zeros((0, 3, 3), np.float32), np.zeros((0, 3, 3), np.float32), m)
+    with pytest.raises(_lib.MiptError, match="cannot open OBJ"):
+        s.add_mesh_obj("/nonexistent/cube.obj", (0, 0, 0), (0, 0, 0), (1, 1, 1), m)
+    with pytest.raises(_lib.MiptError, match="cannot open HDR"):
+        s.set_envmap_dir("/nonexistent/")
+    with pytest.raises(_lib.MiptError, match="not committed"):
+        s.trace_closest(np.zeros((1, 3)), np.ones((1, 3)))
+    pos, nrm = G.cube_mesh()
+    s.add_mesh(pos, nrm, m)
+    s.commit(devices=())
+    # the product path fails loudly when no HIP device backs the scene: there is no CPU fallback
+    with pytest.raises(_lib.MiptError, match="HIP device required"):
+        s.trace_closest(np.zeros((1, 3)), np.ones((1, 3)))
+    with pytest.raises(_lib.MiptError, match="HIP device required"):
+        s.render(make_config(8, 8, 1))
+
+
+def test_product_does_not_reference_the_oracle():
+    pkg = os.path.join(ROOT, "cuda_path_tracer_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".h", ".cpp", ".hip")) or f == "Makefile":
+                text = open(os.path.join(dirpath, f), errors="replace").read()
+                assert "liboracle" not in text and "oracle/" not in text and "import oracle" not in text \
+                    and "from oracle" not in text, os.path.join(dirpath, f)
