@@ -58,18 +58,47 @@ __global__ __launch_bounds__(kExtendBlock, 5) void k_extend(DScene sc, const f4 
     unsigned int hit_tris = 0;
 
     bool has_ray = false, exhausted = false;
-    bool start_mesh = false;  // lane must open mesh `m` (or finish the ray when m == n_meshes)
+    bool start_mesh = false;  // lane must open mesh `m`, or store its result when m == n_meshes
     bool pending = false;     // lane sits at an un-culled leaf (leaf_first/leaf_count) waiting for a batched scan
+    bool need_pop = false;    // lane must continue with the node on top of its stack
     int leaf_first = 0, leaf_count = 0;
-    int slot = 0, m = 0, node = 0, sp = 0, prim = -1;
-    KdNode nd = {0u, kLeafTag};  // the 8 bytes of `node`
-    float best = -1.0f;
+    int slot = 0, m = 0, node = 0, sp = 0;
+    int prim = -1, q_prim = -1;      // best mesh triangle / best sphere-or-plane
+    float best = -1.0f, q_t = -1.0f;
+    KdNode nd = {0u, kLeafTag};      // the 8 bytes of `node`
     f3 o = mk3(0.f, 0.f, 0.f), d = mk3(0.f, 0.f, 1.f);
     SlabBox cur;
 #pragma unroll
     for (int k = 0; k < 3; k++) cur.lo[k] = cur.hi[k] = cur.tlo[k] = cur.thi[k] = 0.f;
 
+    // what follows a leaf visit: bt > 0 = accepted hit at triangle bi (mesh.cuh:300 ends this mesh; kernel.cu:149
+    // keeps the earlier mesh on ties), else continue with the stacked far child, else the mesh is exhausted
+    auto after_leaf = [&](float bt, int bi) {
+        if (bt > 0.0f) {
+            if (best < 0.0f || bt < best) { best = bt; prim = bi; }
+            m++;
+            start_mesh = true;
+        } else if (sp == 0 || sp > kStackDepth) {  // (sp > kStackDepth: unreachable for trees of kd_build.cpp)
+            m++;
+            start_mesh = true;
+        } else {
+            need_pop = true;
+        }
+    };
+
     for (;;) {
+        // ---- rays that ran out of meshes: Scene::firstIntersect's result (kernel.cu:145-160) ------------------
+        if (has_ray && start_mesh && m >= sc.n_meshes) {
+            // spheres/planes were evaluated at fetch time; a mesh hit wins ties because meshes come first
+            const bool mesh_wins = (best > 0.0f) && (q_t < 0.0f || best <= q_t);
+            HitRec h;
+            h.t = mesh_wins ? best : q_t;
+            h.prim = mesh_wins ? prim : q_prim;
+            hits[slot] = h;
+            if (COUNT) hit_tris += mesh_wins ? 1u : 0u;
+            has_ray = false;
+            start_mesh = false;
+        }
         // ---- refill idle lanes from the global work counter --------------------------------------------
         const unsigned long long idle = __ballot(!has_ray);
         if (idle != 0ull && !exhausted) {
@@ -88,8 +117,22 @@ __global__ __launch_bounds__(kExtendBlock, 5) void k_extend(DScene sc, const f4 
                     d = mk3(d4.x, d4.y, d4.z);
                     best = -1.0f;
                     prim = -1;
+                    q_t = -1.0f;
+                    q_prim = -1;
+                    for (int i = 0; i < sc.n_spheres; i++) {  // kernel.cu:151-154
+                        const f4 sp4 = sc.spheres[2 * i];
+                        const float t = sphere_t(mk3(sp4.x, sp4.y, sp4.z), sp4.w, o, d);
+                        if (t > 0.0f && (q_t < 0.0f || t < q_t)) { q_t = t; q_prim = sc.total_tris + i; }
+                    }
+                    for (int i = 0; i < sc.n_planes; i++) {   // kernel.cu:155-158
+                        const f4 p = sc.planes[2 * i], pn = sc.planes[2 * i + 1];
+                        const float t = plane_t(mk3(p.x, p.y, p.z), mk3(pn.x, pn.y, pn.z), o, d);
+                        if (t > 0.0f && (q_t < 0.0f || t < q_t)) { q_t = t; q_prim = sc.total_tris + sc.n_spheres + i; }
+                    }
                     m = 0;
                     start_mesh = true;
+                    pending = false;
+                    need_pop = false;
                     has_ray = true;
                 }
                 if (base + n_idle >= n) exhausted = true;  // wave-uniform: base and n_idle are
@@ -99,88 +142,56 @@ __global__ __launch_bounds__(kExtendBlock, 5) void k_extend(DScene sc, const f4 
             if (exhausted) break;
             continue;
         }
+        // ---- open the next mesh: root box test (mesh.cuh:254) -------------------------------------------------
+        if (has_ray && start_mesh && m < sc.n_meshes) {
+            node = sc.meshes[m].root;
+            nd = sc.nodes[node];
+            load_slab(sc, node, o, d, cur);
+            if (slab_hit(cur, o, d) > 0.0f) {
+                sp = 0;
+                start_mesh = false;
+                if (COUNT) { tc.pops++; tc.nodes++; }
+            } else {
+                m++;  // the ray misses this mesh's root box
+            }
+        }
         // ---- postponed leaf scans: run the candidate loop only when enough lanes wait for one -------------------
         // (about 9 of 10 leaf visits are culled; scanning the rest one by one would run the loop at ~10% lane use)
         {
             const int n_pend = __popcll(__ballot(pending));
-            const int n_trav = __popcll(__ballot(has_ray && !pending));
+            const int n_trav = __popcll(__ballot(has_ray && !pending && !start_mesh));
             if (n_pend >= tune.leaf_batch_lanes || (n_pend > 0 && n_trav < tune.leaf_batch_lanes)) {
                 if (pending) {
                     float bt;
                     int bi;
                     leaf_scan(sc, leaf_first, leaf_count, o, d, cur, bt, bi);
                     pending = false;
-                    if (bt > 0.0f) {  // mesh.cuh:300 first accepting leaf ends this mesh; kernel.cu:149 merge (strict '<')
-                        if (best < 0.0f || bt < best) { best = bt; prim = bi; }
-                        m++;
-                        start_mesh = true;
-                    } else if (sp == 0 || sp > kStackDepth) {  // stack empty (or, unreachable, overflowed): mesh missed
-                        m++;
-                        start_mesh = true;
-                    } else {
-                        sp--;
-                        node = stk.pop(sp);
-                        nd = sc.nodes[node];
-                        load_slab(sc, node, o, d, cur);
-                        if (COUNT) { tc.pops++; tc.nodes++; }
-                    }
+                    after_leaf(bt, bi);
                 }
             }
         }
-        if (!has_ray || pending) continue;
-
-        // ---- one step of the lane's state machine --------------------------------------------------------
-        if (start_mesh) {
-            if (m >= sc.n_meshes) {  // Scene::firstIntersect tail: spheres, then planes (kernel.cu:151-158)
-                for (int i = 0; i < sc.n_spheres; i++) {
-                    const f4 s = sc.spheres[2 * i];
-                    const float t = sphere_t(mk3(s.x, s.y, s.z), s.w, o, d);
-                    if (t > 0.0f && (best < 0.0f || t < best)) { best = t; prim = sc.total_tris + i; }
-                }
-                for (int i = 0; i < sc.n_planes; i++) {
-                    const f4 p = sc.planes[2 * i], pn = sc.planes[2 * i + 1];
-                    const float t = plane_t(mk3(p.x, p.y, p.z), mk3(pn.x, pn.y, pn.z), o, d);
-                    if (t > 0.0f && (best < 0.0f || t < best)) { best = t; prim = sc.total_tris + sc.n_spheres + i; }
-                }
-                HitRec h;
-                h.t = best;
-                h.prim = prim;
-                hits[slot] = h;
-                if (COUNT) hit_tris += (prim >= 0 && prim < sc.total_tris) ? 1u : 0u;
-                has_ray = false;
-                continue;
-            }
-            node = sc.meshes[m].root;
+        // ---- continue with the far child that was stacked (mesh.cuh:263): its box is re-read --------------------
+        if (need_pop) {
+            sp--;
+            node = stk.pop(sp);
             nd = sc.nodes[node];
             load_slab(sc, node, o, d, cur);
-            if (!(slab_hit(cur, o, d) > 0.0f)) {  // mesh.cuh:254: the ray misses the mesh's root box
-                m++;
-                continue;
-            }
-            sp = 0;
-            start_mesh = false;
+            need_pop = false;
             if (COUNT) { tc.pops++; tc.nodes++; }
         }
+        if (!has_ray || pending || start_mesh) continue;
+
+        // ---- walk down (at most step_cap steps per round), then the leaf visit ---------------------------------
         descend_to_leaf<LdsStack, COUNT>(sc, o, d, cur, node, nd, sp, stk, tc, tune.step_cap);
         if ((nd.b >> 30) != 3u) continue;  // out of steps for this round: keep walking next round
-        const KdNode leaf = nd;
-        leaf_first = (int)leaf.a;
-        leaf_count = (int)(leaf.b & kIdxMask);
+        leaf_first = (int)nd.a;
+        leaf_count = (int)(nd.b & kIdxMask);
         if (COUNT) { tc.refs += leaf_count; tc.tris += leaf_count; }
         if (!leaf_culled(sc, node, o, d)) {
             pending = true;  // scanned later, together with other lanes' leaves
         } else {
             if (COUNT) tc.culled += leaf_count;
-            if (sp == 0 || sp > kStackDepth) {  // nothing found in this mesh
-                m++;
-                start_mesh = true;
-            } else {
-                sp--;
-                node = stk.pop(sp);
-                nd = sc.nodes[node];
-                load_slab(sc, node, o, d, cur);
-                if (COUNT) { tc.pops++; tc.nodes++; }
-            }
+            after_leaf(-1.0f, -1);
         }
     }
     if (COUNT) flush_counters(tc, hit_tris, ctr);

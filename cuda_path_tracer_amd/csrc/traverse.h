@@ -174,7 +174,8 @@ PT_HD bool leaf_culled(const DScene &sc, int node, f3 o, f3 d) {
         if (fabsf(dd[k]) < 1e-30f) {
             out |= (oo[k] < l) | (oo[k] > h);
         } else {
-            const float t0 = (l - oo[k]) / dd[k], t1 = (h - oo[k]) / dd[k];
+            const float inv = __frcp_rn(dd[k]);  // a 1-ulp reciprocal is plenty: the test is conservative by 2^-12
+            const float t0 = (l - oo[k]) * inv, t1 = (h - oo[k]) * inv;
             tn = fmaxf(tn, fminf(t0, t1));
             tf = fminf(tf, fmaxf(t0, t1));
         }
