@@ -171,9 +171,20 @@ __global__ __launch_bounds__(kExtendBlock, 5) void k_extend(DScene sc, const f4 
             }
         }
         // ---- continue with the far child that was stacked (mesh.cuh:263): its box is re-read --------------------
-        if (need_pop) {
+        // A stacked subtree whose cull box (union of its leaves' cull boxes) the ray misses cannot produce a hit: it
+        // is dropped without being walked -- the continuation is the same as after walking it in vain.  (The
+        // counting variant walks everything so that its counters stay those of the reference traversal.)
+        while (need_pop) {
             sp--;
             node = stk.pop(sp);
+            if (!COUNT && leaf_culled(sc, node, o, d)) {
+                if (sp == 0) {  // nothing left in this mesh
+                    need_pop = false;
+                    m++;
+                    start_mesh = true;
+                }
+                continue;
+            }
             nd = sc.nodes[node];
             load_slab(sc, node, o, d, cur);
             need_pop = false;

@@ -369,6 +369,18 @@ bool HostScene::pack(int n_threads, std::string &err) {
                 tb[2 * a + 1] = std::min(nb[2 * a + 1], hi[a]);
             }
         }
+        // interior nodes: union of the children's cull boxes (children are stored after their parent), so a ray that
+        // misses it cannot find anything in the whole subtree and the stacked subtree can be dropped unvisited
+        for (int64_t i = hm.n_nodes - 1; i >= 0; i--) {
+            const KdNode k = t.nodes[(size_t)i];
+            if ((k.b >> 30) == 3u) continue;
+            const float *l = tight + 8 * (size_t)(k.b & kIdxMask), *r = l + 8;
+            float *tb = tight + 8 * i;
+            for (int a = 0; a < 3; a++) {
+                tb[2 * a] = std::min(l[2 * a], r[2 * a]);
+                tb[2 * a + 1] = std::max(l[2 * a + 1], r[2 * a + 1]);
+            }
+        }
         int32_t *refs = reinterpret_cast<int32_t *>(A + L.refs) + hm.ref_base;
         for (int64_t i = 0; i < hm.n_refs; i++) refs[i] = t.refs[(size_t)i] + (int32_t)hm.tri_base;
         // leaf-ordered plane records: N = cross(b-a, c-a), dd = -dot(N, a) exactly as Triangle::intersect
