@@ -193,7 +193,11 @@ __global__ __launch_bounds__(kExtendBlock, 5) void k_extend(DScene sc, const f4 
         if (!has_ray || pending || start_mesh) continue;
 
         // ---- walk down (at most step_cap steps per round), then the leaf visit ---------------------------------
-        descend_to_leaf<LdsStack, COUNT>(sc, o, d, cur, node, nd, sp, stk, tc, tune.step_cap);
+        const bool sub_culled = descend_to_leaf<LdsStack, COUNT, !COUNT>(sc, o, d, cur, node, nd, sp, stk, tc, tune.step_cap);
+        if (sub_culled) {  // the subtree just entered cannot contain a hit: same continuation as a fruitless visit
+            after_leaf(-1.0f, -1);
+            continue;
+        }
         if ((nd.b >> 30) != 3u) continue;  // out of steps for this round: keep walking next round
         leaf_first = (int)nd.a;
         leaf_count = (int)(nd.b & kIdxMask);

@@ -104,13 +104,16 @@ PT_HD bool inside_triangle(f4 pl, f3 a, f3 b, f3 c, f3 o, f3 d, float t) {
     return true;
 }
 
+PT_HD bool leaf_culled(const DScene &sc, int node, f3 o, f3 d);
+
 // Inner loop of Mesh::intersect (mesh.cuh:265-288): walk from `node` (whose 8 bytes are in `nd`) down towards a
 // leaf, pushing the far child when both children are hit (Q7).  `cur` (bounds + plane parameters of `node`)
 // is updated in place.  Both children sit in one aligned 16-byte pair; its load is issued first and is only
 // consumed after the step's slab arithmetic, which hides most of the node-fetch latency.
-// Stops at a leaf or after `max_steps` steps (then `nd` is still interior).
-template <class Stack, bool COUNT>
-PT_HD void descend_to_leaf(const DScene &sc, f3 o, f3 d, SlabBox &cur, int &node, KdNode &nd, int &sp, Stack &stk,
+// Stops at a leaf or after `max_steps` steps (then `nd` is still interior).  With CULL, returns true as soon as the
+// ray misses the cull box of the subtree it just stepped into (see leaf_culled): nothing can be found below.
+template <class Stack, bool COUNT, bool CULL = false>
+PT_HD bool descend_to_leaf(const DScene &sc, f3 o, f3 d, SlabBox &cur, int &node, KdNode &nd, int &sp, Stack &stk,
                            TravCounters &ctr, int max_steps = 1 << 30) {
     for (int step = 0; (nd.b >> 30) != 3u && step < max_steps; step++) {
         const uint32_t ax = nd.b >> 30;
@@ -149,7 +152,9 @@ PT_HD void descend_to_leaf(const DScene &sc, f3 o, f3 d, SlabBox &cur, int &node
         nd.a = go_right ? pair.r.a : pair.l.a;
         nd.b = go_right ? pair.r.b : pair.l.b;
         if (COUNT) ctr.nodes++;
+        if (CULL && leaf_culled(sc, node, o, d)) return true;
     }
+    return false;
 }
 
 // Leaf loop of Mesh::intersect (mesh.cuh:290-299).  The 16-byte plane records of a leaf are contiguous: four
