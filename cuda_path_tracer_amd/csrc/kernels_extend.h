@@ -59,9 +59,8 @@ __global__ __launch_bounds__(kExtendBlock, 5) void k_extend(DScene sc, const f4 
 
     bool has_ray = false, exhausted = false;
     bool start_mesh = false;  // lane must open mesh `m`, or store its result when m == n_meshes
-    bool pending = false;     // lane sits at an un-culled leaf (leaf_first/leaf_count) waiting for a batched scan
+    bool pending = false;     // lane sits at an un-culled leaf (`nd`) waiting for a batched scan
     bool need_pop = false;    // lane must continue with the node on top of its stack
-    int leaf_first = 0, leaf_count = 0;
     int slot = 0, m = 0, node = 0, sp = 0;
     int prim = -1, q_prim = -1;      // best mesh triangle / best sphere-or-plane
     float best = -1.0f, q_t = -1.0f;
@@ -164,7 +163,7 @@ __global__ __launch_bounds__(kExtendBlock, 5) void k_extend(DScene sc, const f4 
                 if (pending) {
                     float bt;
                     int bi;
-                    leaf_scan(sc, leaf_first, leaf_count, o, d, cur, bt, bi);
+                    leaf_scan(sc, (int)nd.a, (int)(nd.b & kIdxMask), o, d, cur, bt, bi);
                     pending = false;
                     after_leaf(bt, bi);
                 }
@@ -199,13 +198,11 @@ __global__ __launch_bounds__(kExtendBlock, 5) void k_extend(DScene sc, const f4 
             continue;
         }
         if ((nd.b >> 30) != 3u) continue;  // out of steps for this round: keep walking next round
-        leaf_first = (int)nd.a;
-        leaf_count = (int)(nd.b & kIdxMask);
-        if (COUNT) { tc.refs += leaf_count; tc.tris += leaf_count; }
+        if (COUNT) { tc.refs += nd.b & kIdxMask; tc.tris += nd.b & kIdxMask; }
         if (!leaf_culled(sc, node, o, d)) {
             pending = true;  // scanned later, together with other lanes' leaves
         } else {
-            if (COUNT) tc.culled += leaf_count;
+            if (COUNT) tc.culled += nd.b & kIdxMask;
             after_leaf(-1.0f, -1);
         }
     }
