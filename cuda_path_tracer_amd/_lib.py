@@ -21,7 +21,7 @@ class Stats(C.Structure):
     """mipt_stats."""
     _fields_ = [
         ("rays_total", C.c_int64), ("rays_camera", C.c_int64), ("rays_shadow", C.c_int64), ("rays_light", C.c_int64),
-        ("samples", C.c_int64), ("extend_launches", C.c_int64),
+        ("samples", C.c_int64), ("extend_launches", C.c_int64), ("rays_extended", C.c_int64),
         ("ms_total", C.c_double), ("ms_extend", C.c_double), ("ms_other", C.c_double),
         ("ctr_nodes", C.c_int64), ("ctr_pops", C.c_int64), ("ctr_refs", C.c_int64), ("ctr_tris", C.c_int64),
         ("ctr_hits", C.c_int64), ("ctr_culled", C.c_int64),

@@ -255,6 +255,7 @@ int mipt_trace_closest_device(mipt_scene *s, int slot, const float *d_ray_o, con
         HIP_TRY(hipEventElapsedTime(&ms_all, e0, e3));
         HIP_TRY(hipEventElapsedTime(&ms_ext, e1, e2));
         st->rays_total = n;
+        st->rays_extended = n;
         st->extend_launches = 1;
         st->ms_total = ms_all;
         st->ms_extend = ms_ext;
@@ -345,6 +346,7 @@ int mipt_render(mipt_scene *s, const mipt_render_config *cfg, float *out, mipt_s
             st->rays_total += stats[(size_t)g].rays_total; st->rays_camera += stats[(size_t)g].rays_camera;
             st->rays_shadow += stats[(size_t)g].rays_shadow; st->rays_light += stats[(size_t)g].rays_light;
             st->samples += stats[(size_t)g].samples; st->extend_launches += stats[(size_t)g].extend_launches;
+            st->rays_extended += stats[(size_t)g].rays_extended;
             st->ms_total = std::max(st->ms_total, stats[(size_t)g].ms_total);
             st->ms_extend = std::max(st->ms_extend, stats[(size_t)g].ms_extend);
             st->ms_other = std::max(st->ms_other, stats[(size_t)g].ms_other);

@@ -284,6 +284,32 @@ PT_HD float sphere_t(f3 center, float radius, f3 o, f3 d) {
     return (t2 > 0.0f) ? t2 : t1;
 }
 
+// A ray that misses the root box of every mesh (mesh.cuh:254) is decided by the spheres and planes alone.  The
+// wavefront stages that GENERATE rays run this test in their own, fully convergent lanes and answer such rays on
+// the spot, so that only rays with real traversal work reach the (divergent) extend kernel.
+PT_HD bool scene_trivial(const DScene &sc, f3 o, f3 d, float &out_t, int &out_prim) {
+    for (int m = 0; m < sc.n_meshes; m++) {
+        SlabBox b;
+        load_slab(sc, sc.meshes[m].root, o, d, b);
+        if (slab_hit(b, o, d) > 0.0f) return false;
+    }
+    float best = -1.0f;
+    int prim = -1;
+    for (int i = 0; i < sc.n_spheres; i++) {
+        const f4 s = sc.spheres[2 * i];
+        const float t = sphere_t(mk3(s.x, s.y, s.z), s.w, o, d);
+        if (t > 0.0f && (best < 0.0f || t < best)) { best = t; prim = sc.total_tris + i; }
+    }
+    for (int i = 0; i < sc.n_planes; i++) {
+        const f4 p = sc.planes[2 * i], n = sc.planes[2 * i + 1];
+        const float t = plane_t(mk3(p.x, p.y, p.z), mk3(n.x, n.y, n.z), o, d);
+        if (t > 0.0f && (best < 0.0f || t < best)) { best = t; prim = sc.total_tris + sc.n_spheres + i; }
+    }
+    out_t = best;
+    out_prim = prim;
+    return true;
+}
+
 // Scene::firstIntersect (kernel.cu:145-160): meshes, spheres, planes; strict '<' keeps the earlier object.
 // prim: -1 miss; [0,total_tris) triangle; then spheres; then planes.
 template <class Stack, bool COUNT>

@@ -49,6 +49,28 @@ __device__ __forceinline__ int wave_append(bool pred, int *counter) {
     return pred ? base + rank : -1;
 }
 
+// Answer a freshly generated ray on the spot if it is trivial (see scene_trivial), else queue it for extend.
+// Call it from convergent code (all live lanes of the wave together): it appends with one atomic per wave.
+__device__ __forceinline__ void emit_ray(const DScene &sc, bool valid, f3 o, f3 d, HitRec *hit_slot, int queue_value, int *queue,
+                                         int *queue_count, int *trivial_count) {
+    bool need_extend = false;
+    if (valid) {
+        float t;
+        int prim;
+        if (scene_trivial(sc, o, d, t, prim)) {
+            HitRec h;
+            h.t = t;
+            h.prim = prim;
+            *hit_slot = h;
+        } else {
+            need_extend = true;
+        }
+    }
+    const int qi = wave_append(need_extend, queue_count);
+    if (need_extend) queue[qi] = queue_value;
+    if (trivial_count) (void)wave_append(valid && !need_extend, trivial_count);
+}
+
 struct PassParams {
     int W, H, npix;
     int spp;             // normalisation constant
@@ -66,9 +88,10 @@ struct WfBuffers {
     uint32_t *path_rng, *sh_mask;
     f4 *sh_o, *sh_d, *sh_target, *sh_contrib;
     HitRec *sh_hit;
-    int *q_cam[2], *q_light[2], *q_shadow;
+    int *q_cam[2], *q_light[2], *q_shadow;  // paths alive at a vertex (stage bookkeeping) / shadow rays to trace
+    int *q_ext_cam, *q_ext_light;           // the subset of camera / light rays that needs the extend kernel
     int *counts;                 // per-stage queue counts of the current pass
-    unsigned long long *totals;  // [0] camera rays [1] shadow rays [2] light rays
+    unsigned long long *totals;  // [0] camera rays [1] shadow rays [2] light rays [3] rays traced by k_extend
     f4 *lv_pos, *lv_nrm, *lv_T;  // light vertices [path*Dl + j]: (pos, valid) (normal, pdf) (throughput, -)
     f4 *l_o, *l_d, *l_state;     // light rays; l_state = (emission dir, pdf carried to the next vertex)
     HitRec *l_hit;
@@ -79,7 +102,10 @@ constexpr int kCntCam = 0;      // + i  (camera queue feeding vertex i), i <= 16
 constexpr int kCntShadow = 20;  // + i
 constexpr int kCntLight = 40;   // + i
 constexpr int kCntWork = 64;    // + launch index within the pass: ray cursor of each persistent extend launch
-constexpr int kCntTotal = 128;
+constexpr int kCntExtCam = 128;     // + i: camera rays of vertex i that need the extend kernel (not trivially decided)
+constexpr int kCntExtLight = 148;   // + i
+constexpr int kCntShadowTriv = 168; // + i: shadow rays answered on the spot
+constexpr int kCntTotal = 192;
 
 __global__ __launch_bounds__(kBlock) void k_raygen(DScene sc, PassParams pp, WfBuffers b) {
     const int pid = blockIdx.x * kBlock + threadIdx.x;
@@ -105,6 +131,7 @@ __global__ __launch_bounds__(kBlock) void k_raygen(DScene sc, PassParams pp, WfB
     b.sh_mask[pid] = 0u;
     if (pp.Dl == 0) b.q_cam[0][pid] = pid;
     else b.q_light[0][pid] = pid;
+    emit_ray(sc, true, ld3(sc.cam_eye), dir, &b.path_hit[pid], pid, b.q_ext_cam, &b.counts[kCntExtCam + 0], nullptr);
 }
 
 __global__ __launch_bounds__(kBlock) void k_lightgen(DScene sc, PassParams pp, WfBuffers b) {
@@ -125,6 +152,7 @@ __global__ __launch_bounds__(kBlock) void k_lightgen(DScene sc, PassParams pp, W
         b.lv_pos[(size_t)pid * pp.Dl + j] = f4{0.f, 0.f, 0.f, -1.f};
         b.lv_T[(size_t)pid * pp.Dl + j] = f4{0.f, 0.f, 0.f, 0.f};
     }
+    emit_ray(sc, true, xyz(sc.lights[2 * li]), norm3(ldir), &b.l_hit[pid], pid, b.q_ext_light, &b.counts[kCntExtLight + 0], nullptr);
 }
 
 // light sub-path vertex i (kernel.cu:184-231)
@@ -136,6 +164,7 @@ __global__ __launch_bounds__(kBlock) void k_light_shade(DScene sc, PassParams pp
         const int idx = base + threadIdx.x;
         bool cont = false, to_cam = false;
         int pid = -1;
+        f3 nro = mk3(0.f, 0.f, 0.f), nrd = mk3(0.f, 0.f, 1.f);  // the bounce ray, when the walk continues
         if (idx < n) {
             pid = qin[idx];
             const HitRec h = b.l_hit[pid];
@@ -178,8 +207,10 @@ __global__ __launch_bounds__(kBlock) void k_light_shade(DScene sc, PassParams pp
                             if (ok) T = Tprev * s.ks;
                         }
                         if (ok) {
-                            b.l_o[pid] = mk4(s.pos + s.nrm * kEps, 0.f);
-                            b.l_d[pid] = mk4(norm3(od), 0.f);
+                            nro = s.pos + s.nrm * kEps;
+                            nrd = norm3(od);
+                            b.l_o[pid] = mk4(nro, 0.f);
+                            b.l_d[pid] = mk4(nrd, 0.f);
                             b.l_state[pid] = mk4(xyz(st), pdf * pdf_b);
                             cont = true;
                         }
@@ -193,6 +224,7 @@ __global__ __launch_bounds__(kBlock) void k_light_shade(DScene sc, PassParams pp
         }
         const int qi = wave_append(cont, &b.counts[kCntLight + i + 1]);
         if (cont) qout[qi] = pid;
+        emit_ray(sc, cont, nro, nrd, cont ? &b.l_hit[pid] : nullptr, pid, b.q_ext_light, &b.counts[kCntExtLight + i + 1], nullptr);
         if (i == 0) {
             const int ci = wave_append(to_cam, &b.counts[kCntCam + 0]);
             if (to_cam) b.q_cam[0][ci] = pid;
@@ -210,6 +242,7 @@ __global__ __launch_bounds__(kBlock) void k_shade(DScene sc, PassParams pp, WfBu
         bool cont = false;
         int pid = -1;
         uint32_t mask = 0u;
+        f3 nro = mk3(0.f, 0.f, 0.f), nrd = mk3(0.f, 0.f, 1.f);  // the next camera ray, when the path continues
         if (idx < n) {
             pid = qin[idx];
             const HitRec h = b.path_hit[pid];
@@ -288,8 +321,10 @@ __global__ __launch_bounds__(kBlock) void k_shade(DScene sc, PassParams pp, WfBu
                     }
                     b.path_rng[pid] = rng.draw;
                     if (cont) {
-                        b.path_o[pid] = mk4(s.pos + s.nrm * kEps, 0.f);
-                        b.path_d[pid] = mk4(norm3(od), 0.f);
+                        nro = s.pos + s.nrm * kEps;
+                        nrd = norm3(od);
+                        b.path_o[pid] = mk4(nro, 0.f);
+                        b.path_d[pid] = mk4(nrd, 0.f);
                         b.path_T[pid] = mk4(Tc, pc);
                     }
                 }
@@ -298,10 +333,13 @@ __global__ __launch_bounds__(kBlock) void k_shade(DScene sc, PassParams pp, WfBu
         }
         const int qi = wave_append(cont, &b.counts[kCntCam + i + 1]);
         if (cont) qout[qi] = pid;
+        emit_ray(sc, cont, nro, nrd, cont ? &b.path_hit[pid] : nullptr, pid, b.q_ext_cam, &b.counts[kCntExtCam + i + 1], nullptr);
         for (int k = 0; k < pp.K; k++) {  // batched shadow rays: one append per slot kind keeps waves converged
             const bool emit = (mask >> k) & 1u;
-            const int si = wave_append(emit, &b.counts[kCntShadow + i]);
-            if (emit) b.q_shadow[si] = pid * pp.K + k;
+            const size_t si = emit ? (size_t)pid * pp.K + k : 0;
+            const f3 so = emit ? xyz(b.sh_o[si]) : nro, sd = emit ? xyz(b.sh_d[si]) : nrd;
+            emit_ray(sc, emit, so, sd, emit ? &b.sh_hit[si] : nullptr, (int)si, b.q_shadow, &b.counts[kCntShadow + i],
+                     &b.counts[kCntShadowTriv + i]);
         }
     }
 }
@@ -353,12 +391,15 @@ __global__ __launch_bounds__(kBlock) void k_accumulate(PassParams pp, WfBuffers 
 
 __global__ void k_tally(WfBuffers b, int Dc, int Dl) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    unsigned long long cam = 0, sh = 0, li = 0;
-    for (int i = 0; i < Dc; i++) { cam += (unsigned long long)b.counts[kCntCam + i]; sh += (unsigned long long)b.counts[kCntShadow + i]; }
+    unsigned long long cam = 0, sh = 0, li = 0, ext = 0;
+    for (int i = 0; i < Dc; i++) { cam += (unsigned long long)b.counts[kCntCam + i]; sh += (unsigned long long)b.counts[kCntShadow + i] + (unsigned long long)b.counts[kCntShadowTriv + i]; }
     for (int i = 0; i < Dl; i++) li += (unsigned long long)b.counts[kCntLight + i];
+    for (int i = 0; i < Dc; i++) ext += (unsigned long long)b.counts[kCntExtCam + i] + (unsigned long long)b.counts[kCntShadow + i];
+    for (int i = 0; i < Dl; i++) ext += (unsigned long long)b.counts[kCntExtLight + i];
     b.totals[0] += cam;
     b.totals[1] += sh;
     b.totals[2] += li;
+    b.totals[3] += ext;
 }
 
 __global__ __launch_bounds__(kBlock) void k_env_lookup(DScene sc, const float *dirs, int64_t n, float *rgb) {
@@ -419,15 +460,16 @@ int wavefront_render(const HostScene &hs, DeviceCtx &dc, const mipt_render_confi
     sizes[10] = P * K * sizeof(HitRec);
     sizes[12] = sizes[13] = P * 4;
     sizes[14] = P * K * 4;
+    sizes[25] = P * 4;
     sizes[17] = kCntTotal * 4 + 64;
     if (Dl > 0) {
-        sizes[15] = sizes[16] = P * 4;
+        sizes[15] = sizes[16] = sizes[26] = P * 4;
         sizes[18] = sizes[19] = sizes[20] = P * Dl * sizeof(f4);
         sizes[21] = sizes[22] = sizes[24] = P * sizeof(f4);
         sizes[23] = P * sizeof(HitRec);
     }
-    static_assert(sizeof(dc.wf) / sizeof(dc.wf[0]) >= 25, "wf buffer table too small");
-    for (int i = 0; i < 25; i++)
+    static_assert(sizeof(dc.wf) / sizeof(dc.wf[0]) >= 27, "wf buffer table too small");
+    for (int i = 0; i < 27; i++)
         if (sizes[i]) WF_TRY(dc.wf[i].reserve(sizes[i]));
     WfBuffers b;
     memset(&b, 0, sizeof(b));
@@ -437,6 +479,7 @@ int wavefront_render(const HostScene &hs, DeviceCtx &dc, const mipt_render_confi
     b.sh_hit = dc.wf[10].as<HitRec>(); b.sh_mask = dc.wf[11].as<uint32_t>();
     b.q_cam[0] = dc.wf[12].as<int>(); b.q_cam[1] = dc.wf[13].as<int>(); b.q_shadow = dc.wf[14].as<int>();
     b.q_light[0] = dc.wf[15].as<int>(); b.q_light[1] = dc.wf[16].as<int>();
+    b.q_ext_cam = dc.wf[25].as<int>(); b.q_ext_light = dc.wf[26].as<int>();
     b.counts = dc.wf[17].as<int>();
     b.totals = reinterpret_cast<unsigned long long *>(dc.wf[17].as<char>() + kCntTotal * 4 + 8);
     b.lv_pos = dc.wf[18].as<f4>(); b.lv_nrm = dc.wf[19].as<f4>(); b.lv_T = dc.wf[20].as<f4>();
@@ -477,12 +520,12 @@ int wavefront_render(const HostScene &hs, DeviceCtx &dc, const mipt_render_confi
         if (Dl > 0) {
             hipLaunchKernelGGL(k_lightgen, dim3(full_grid), dim3(kBlock), 0, sm, dc.view, pp, b);
             for (int i = 0; i < Dl; i++) {
-                extend(b.l_o, b.l_d, b.q_light[i & 1], &b.counts[kCntLight + i], b.l_hit, np);
+                extend(b.l_o, b.l_d, b.q_ext_light, &b.counts[kCntExtLight + i], b.l_hit, np);
                 hipLaunchKernelGGL(k_light_shade, dim3(path_grid), dim3(kBlock), 0, sm, dc.view, pp, b, i);
             }
         }
         for (int i = 0; i < Dc; i++) {
-            extend(b.path_o, b.path_d, b.q_cam[i & 1], &b.counts[kCntCam + i], b.path_hit, np);
+            extend(b.path_o, b.path_d, b.q_ext_cam, &b.counts[kCntExtCam + i], b.path_hit, np);
             hipLaunchKernelGGL(k_shade, dim3(path_grid), dim3(kBlock), 0, sm, dc.view, pp, b, i);
             extend(b.sh_o, b.sh_d, b.q_shadow, &b.counts[kCntShadow + i], b.sh_hit, np * K);
             hipLaunchKernelGGL(k_resolve, dim3(path_grid), dim3(kBlock), 0, sm, pp, b, i);
@@ -495,7 +538,7 @@ int wavefront_render(const HostScene &hs, DeviceCtx &dc, const mipt_render_confi
     WF_TRY(hipEventRecord(ev_end, sm));
     WF_TRY(hipStreamSynchronize(sm));
     if (st) {
-        unsigned long long tot[3] = {0, 0, 0};
+        unsigned long long tot[4] = {0, 0, 0, 0};
         WF_TRY(hipMemcpy(tot, b.totals, sizeof(tot), hipMemcpyDeviceToHost));
         float ms = 0.f;
         WF_TRY(hipEventElapsedTime(&ms, ev_begin, ev_end));
@@ -508,6 +551,7 @@ int wavefront_render(const HostScene &hs, DeviceCtx &dc, const mipt_render_confi
         st->rays_camera = (int64_t)tot[0];
         st->rays_shadow = (int64_t)tot[1];
         st->rays_light = (int64_t)tot[2];
+        st->rays_extended = (int64_t)tot[3];
         st->rays_total = st->rays_camera + st->rays_shadow + st->rays_light;
         st->samples = n_samples * npix;
         st->extend_launches = (int64_t)ext_ev.size();

@@ -40,6 +40,8 @@ typedef struct mipt_stats {
     int64_t rays_camera, rays_shadow, rays_light;
     int64_t samples;         /* pixel-samples rendered by this call                              */
     int64_t extend_launches; /* launches of the kd closest-hit kernel                            */
+    int64_t rays_extended;   /* of rays_total: rays traced by that kernel (the rest miss every mesh's root box and are
+                                answered by the stage that generated them)                           */
     double ms_total;         /* GPU time of the whole call (HIP events on the scene's stream)    */
     double ms_extend;        /* summed GPU time of the closest-hit kernel launches               */
     double ms_other;         /* raygen/shade/connect/resolve/accumulate                          */

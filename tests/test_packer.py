@@ -96,8 +96,8 @@ def test_cabi_exports_every_declared_symbol():
 
 
 def test_cabi_struct_sizes_match_header():
-    # mipt_render_config: 12 x int32; mipt_stats: 6 x int64 + 3 x double + 6 x int64
-    assert C.sizeof(_lib.RenderConfig) == 48 and C.sizeof(_lib.Stats) == 15 * 8
+    # mipt_render_config: 12 x int32; mipt_stats: 7 x int64 + 3 x double + 6 x int64
+    assert C.sizeof(_lib.RenderConfig) == 48 and C.sizeof(_lib.Stats) == 16 * 8
 
 
 def test_error_behaviour_without_device():
