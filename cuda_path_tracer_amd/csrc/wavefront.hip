@@ -448,7 +448,9 @@ int wavefront_render(const HostScene &hs, DeviceCtx &dc, const mipt_render_confi
     WF_TRY(hipSetDevice(dc.device));
     if (n_samples == 0 || Dc == 0) return 0;
     int S = cfg.samples_per_pass;
-    if (S <= 0) S = (int)std::max<int64_t>(1, ((int64_t)1 << 21) / npix);
+    // auto: ~16 M paths per pass.  The persistent extend kernel holds ~330 k rays at a time; queues much shorter than
+    // ~10x that spend most of their launch in ramp-up and tail (1080p: 1 sample/pass 122 -> 8 samples/pass 202 Msamples/s)
+    if (S <= 0) S = (int)std::max<int64_t>(1, ((int64_t)1 << 24) / npix);
     S = (int)std::min<int64_t>(std::min<int64_t>(S, n_samples), std::max<int64_t>(1, ((int64_t)1 << 27) / ((int64_t)npix * K)));
     const size_t P = (size_t)S * npix;
 
