@@ -33,26 +33,51 @@
 namespace mipt {
 namespace {
 
-constexpr int kBlock = 256;
+constexpr int kBlock = 512;
 
-// ---- queue append: ballot + mbcnt rank + one atomic per wave --------------------------------------
-__device__ __forceinline__ int wave_append(bool pred, int *counter) {
+// ---- queue append: ballot + mbcnt rank inside a wave, LDS scan over the block's waves, ONE atomic per block ----
+// Same-address atomics complete at ~88 M/s on MI355X (scripts/micro/atomic_bench.hip): one per wave capped the
+// shading kernels at ~5.6 G paths/s per queue, one per 512-thread block does not.
+// Every thread of the block must call it (convergent); `lds` holds 2 * (kWaves + 1) ints and `phase` alternates
+// between its halves so that back-to-back appends need no third barrier.
+constexpr int kWaves = kBlock / 64;
+
+__device__ __forceinline__ int block_append(bool pred, int *counter, int *lds, int &phase) {
+    int *slot = lds + phase * (kWaves + 1);
+    phase ^= 1;
     const unsigned long long mask = __ballot(pred);
-    if (mask == 0ull) return -1;
-    const int n = __popcll(mask);
-    const int leader = __ffsll((long long)mask) - 1;
-    const int lane = (int)(threadIdx.x & 63u);
-    int base = 0;
-    if (lane == leader) base = atomicAdd(counter, n);
-    base = __shfl(base, leader, 64);
+    const int lane = (int)(threadIdx.x & 63u), wave = (int)(threadIdx.x >> 6);
+    if (lane == 0) slot[wave] = __popcll(mask);
+    __syncthreads();
+    if (wave == 0) {
+        const int c = lane < kWaves ? slot[lane] : 0;
+        int incl = c;
+#pragma unroll
+        for (int off = 1; off < kWaves; off <<= 1) {
+            const int t = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += t;
+        }
+        const int total = __shfl(incl, kWaves - 1, 64);
+        int base = 0;
+        if (lane == 0 && total > 0) base = atomicAdd(counter, total);
+        base = __shfl(base, 0, 64);
+        if (lane < kWaves) slot[lane] = base + incl - c;
+    }
+    __syncthreads();
     const int rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned int)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)mask, 0u));
-    return pred ? base + rank : -1;
+    return pred ? slot[wave] + rank : -1;
+}
+
+__device__ __forceinline__ int wave_sum_i(int v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
 }
 
 // Answer a freshly generated ray on the spot if it is trivial (see scene_trivial), else queue it for extend.
-// Call it from convergent code (all live lanes of the wave together): it appends with one atomic per wave.
-__device__ __forceinline__ void emit_ray(const DScene &sc, bool valid, f3 o, f3 d, HitRec *hit_slot, int queue_value, int *queue,
-                                         int *queue_count, int *trivial_count) {
+// Call it from block-convergent code.  Returns true when the ray was answered here (callers tally those).
+__device__ __forceinline__ bool emit_ray(const DScene &sc, bool valid, f3 o, f3 d, HitRec *hit_slot, int queue_value, int *queue,
+                                         int *queue_count, int *lds, int &phase) {
     bool need_extend = false;
     if (valid) {
         float t;
@@ -66,9 +91,9 @@ __device__ __forceinline__ void emit_ray(const DScene &sc, bool valid, f3 o, f3 
             need_extend = true;
         }
     }
-    const int qi = wave_append(need_extend, queue_count);
+    const int qi = block_append(need_extend, queue_count, lds, phase);
     if (need_extend) queue[qi] = queue_value;
-    if (trivial_count) (void)wave_append(valid && !need_extend, trivial_count);
+    return valid && !need_extend;
 }
 
 struct PassParams {
@@ -106,58 +131,75 @@ constexpr int kCntExtCam = 128;     // + i: camera rays of vertex i that need th
 constexpr int kCntExtLight = 148;   // + i
 constexpr int kCntShadowTriv = 168; // + i: shadow rays answered on the spot
 constexpr int kCntTotal = 192;
+constexpr int kCntPad = 64;  // counters sit 256 B apart: atomics on neighbouring words of one line serialise like same-address ones
 
 __global__ __launch_bounds__(kBlock) void k_raygen(DScene sc, PassParams pp, WfBuffers b) {
+    __shared__ int ap_lds[2 * (kWaves + 1)];
+    int phase = 0;
     const int pid = blockIdx.x * kBlock + threadIdx.x;
     const int n = pp.n_slots * pp.npix;
     if (pid == 0) {
-        if (pp.Dl == 0) b.counts[kCntCam + 0] = n;
-        else b.counts[kCntLight + 0] = n;
+        if (pp.Dl == 0) b.counts[kCntPad * (kCntCam + 0)] = n;
+        else b.counts[kCntPad * (kCntLight + 0)] = n;
     }
-    if (pid >= n) return;
-    const int slot = pid / pp.npix, pixel = pid - slot * pp.npix;
-    const int sample = pp.sample0 + slot * pp.sample_stride;
-    const int row = pixel / pp.W, col = pixel - row * pp.W;
-    Rng rng;
-    rng.init(pp.seed, (uint32_t)pixel, (uint32_t)sample, 0u);
-    const float jx = rng.u();  // Q18: first draw -> X, second -> Y
-    const float jy = rng.u();
-    const f3 dir = norm3(camera_dir(sc, (float)col + jx, (float)row + jy, pp.W, pp.H));
-    b.path_o[pid] = mk4(ld3(sc.cam_eye), 0.f);
-    b.path_d[pid] = mk4(dir, 0.f);
-    b.path_T[pid] = f4{1.f, 1.f, 1.f, 1.f};
-    b.path_rad[pid] = f4{0.f, 0.f, 0.f, 0.f};
-    b.path_rng[pid] = rng.draw;
-    b.sh_mask[pid] = 0u;
-    if (pp.Dl == 0) b.q_cam[0][pid] = pid;
-    else b.q_light[0][pid] = pid;
-    emit_ray(sc, true, ld3(sc.cam_eye), dir, &b.path_hit[pid], pid, b.q_ext_cam, &b.counts[kCntExtCam + 0], nullptr);
+    const bool live = pid < n;
+    f3 dir = mk3(0.f, 0.f, 1.f);
+    if (live) {
+        const int slot = pid / pp.npix, pixel = pid - slot * pp.npix;
+        const int sample = pp.sample0 + slot * pp.sample_stride;
+        const int row = pixel / pp.W, col = pixel - row * pp.W;
+        Rng rng;
+        rng.init(pp.seed, (uint32_t)pixel, (uint32_t)sample, 0u);
+        const float jx = rng.u();  // Q18: first draw -> X, second -> Y
+        const float jy = rng.u();
+        dir = norm3(camera_dir(sc, (float)col + jx, (float)row + jy, pp.W, pp.H));
+        b.path_o[pid] = mk4(ld3(sc.cam_eye), 0.f);
+        b.path_d[pid] = mk4(dir, 0.f);
+        b.path_T[pid] = f4{1.f, 1.f, 1.f, 1.f};
+        b.path_rad[pid] = f4{0.f, 0.f, 0.f, 0.f};
+        b.path_rng[pid] = rng.draw;
+        b.sh_mask[pid] = 0u;
+        if (pp.Dl == 0) b.q_cam[0][pid] = pid;
+        else b.q_light[0][pid] = pid;
+    }
+    (void)emit_ray(sc, live, ld3(sc.cam_eye), dir, live ? &b.path_hit[pid] : nullptr, pid, b.q_ext_cam,
+                   &b.counts[kCntPad * (kCntExtCam + 0)], ap_lds, phase);
 }
 
 __global__ __launch_bounds__(kBlock) void k_lightgen(DScene sc, PassParams pp, WfBuffers b) {
+    __shared__ int ap_lds[2 * (kWaves + 1)];
+    int phase = 0;
     const int pid = blockIdx.x * kBlock + threadIdx.x;
     const int n = pp.n_slots * pp.npix;
-    if (pid >= n) return;
-    const int slot = pid / pp.npix, pixel = pid - slot * pp.npix;
-    Rng rng;
-    rng.init(pp.seed, (uint32_t)pixel, (uint32_t)(pp.sample0 + slot * pp.sample_stride), b.path_rng[pid]);
-    int li = (int)(rng.u() * ((float)sc.n_lights));  // kernel.cu:178
-    if (li >= sc.n_lights) li = sc.n_lights - 1;      // Q17 clamp
-    const f3 ldir = light_sample_dir(rng);
-    b.l_o[pid] = mk4(xyz(sc.lights[2 * li]), 0.f);
-    b.l_d[pid] = mk4(norm3(ldir), 0.f);               // Ray ctor normalises again (ray.cuh:10)
-    b.l_state[pid] = mk4(ldir, as_f32((uint32_t)li));
-    b.path_rng[pid] = rng.draw;
-    for (int j = 0; j < pp.Dl; j++) {
-        b.lv_pos[(size_t)pid * pp.Dl + j] = f4{0.f, 0.f, 0.f, -1.f};
-        b.lv_T[(size_t)pid * pp.Dl + j] = f4{0.f, 0.f, 0.f, 0.f};
+    const bool live = pid < n;
+    f3 lo = mk3(0.f, 0.f, 0.f), ld = mk3(0.f, 0.f, 1.f);
+    if (live) {
+        const int slot = pid / pp.npix, pixel = pid - slot * pp.npix;
+        Rng rng;
+        rng.init(pp.seed, (uint32_t)pixel, (uint32_t)(pp.sample0 + slot * pp.sample_stride), b.path_rng[pid]);
+        int li = (int)(rng.u() * ((float)sc.n_lights));  // kernel.cu:178
+        if (li >= sc.n_lights) li = sc.n_lights - 1;      // Q17 clamp
+        const f3 ldir = light_sample_dir(rng);
+        lo = xyz(sc.lights[2 * li]);
+        ld = norm3(ldir);                                 // Ray ctor normalises again (ray.cuh:10)
+        b.l_o[pid] = mk4(lo, 0.f);
+        b.l_d[pid] = mk4(ld, 0.f);
+        b.l_state[pid] = mk4(ldir, as_f32((uint32_t)li));
+        b.path_rng[pid] = rng.draw;
+        for (int j = 0; j < pp.Dl; j++) {
+            b.lv_pos[(size_t)pid * pp.Dl + j] = f4{0.f, 0.f, 0.f, -1.f};
+            b.lv_T[(size_t)pid * pp.Dl + j] = f4{0.f, 0.f, 0.f, 0.f};
+        }
     }
-    emit_ray(sc, true, xyz(sc.lights[2 * li]), norm3(ldir), &b.l_hit[pid], pid, b.q_ext_light, &b.counts[kCntExtLight + 0], nullptr);
+    (void)emit_ray(sc, live, lo, ld, live ? &b.l_hit[pid] : nullptr, pid, b.q_ext_light, &b.counts[kCntPad * (kCntExtLight + 0)],
+                   ap_lds, phase);
 }
 
 // light sub-path vertex i (kernel.cu:184-231)
 __global__ __launch_bounds__(kBlock) void k_light_shade(DScene sc, PassParams pp, WfBuffers b, int i) {
-    const int n = b.counts[kCntLight + i];
+    __shared__ int ap_lds[2 * (kWaves + 1)];
+    int phase = 0;
+    const int n = b.counts[kCntPad * (kCntLight + i)];
     const int *qin = b.q_light[i & 1];
     int *qout = b.q_light[(i + 1) & 1];
     for (int base = blockIdx.x * kBlock; base < n; base += gridDim.x * kBlock) {
@@ -222,11 +264,12 @@ __global__ __launch_bounds__(kBlock) void k_light_shade(DScene sc, PassParams pp
                 b.lv_T[vi] = mk4(T, 0.f);
             }
         }
-        const int qi = wave_append(cont, &b.counts[kCntLight + i + 1]);
+        const int qi = block_append(cont, &b.counts[kCntPad * (kCntLight + i + 1)], ap_lds, phase);
         if (cont) qout[qi] = pid;
-        emit_ray(sc, cont, nro, nrd, cont ? &b.l_hit[pid] : nullptr, pid, b.q_ext_light, &b.counts[kCntExtLight + i + 1], nullptr);
+        (void)emit_ray(sc, cont, nro, nrd, cont ? &b.l_hit[pid] : nullptr, pid, b.q_ext_light,
+                       &b.counts[kCntPad * (kCntExtLight + i + 1)], ap_lds, phase);
         if (i == 0) {
-            const int ci = wave_append(to_cam, &b.counts[kCntCam + 0]);
+            const int ci = block_append(to_cam, &b.counts[kCntPad * (kCntCam + 0)], ap_lds, phase);
             if (to_cam) b.q_cam[0][ci] = pid;
         }
     }
@@ -234,7 +277,10 @@ __global__ __launch_bounds__(kBlock) void k_light_shade(DScene sc, PassParams pp
 
 // camera sub-path vertex i (kernel.cu:239-303)
 __global__ __launch_bounds__(kBlock) void k_shade(DScene sc, PassParams pp, WfBuffers b, int i) {
-    const int n = b.counts[kCntCam + i];
+    __shared__ int ap_lds[2 * (kWaves + 1)];
+    int phase = 0;
+    int n_trivial = 0;  // shadow rays answered here; one atomic per wave at the end
+    const int n = b.counts[kCntPad * (kCntCam + i)];
     const int *qin = b.q_cam[i & 1];
     int *qout = b.q_cam[(i + 1) & 1];
     for (int base = blockIdx.x * kBlock; base < n; base += gridDim.x * kBlock) {
@@ -331,22 +377,26 @@ __global__ __launch_bounds__(kBlock) void k_shade(DScene sc, PassParams pp, WfBu
             }
             b.sh_mask[pid] = mask;
         }
-        const int qi = wave_append(cont, &b.counts[kCntCam + i + 1]);
+        const int qi = block_append(cont, &b.counts[kCntPad * (kCntCam + i + 1)], ap_lds, phase);
         if (cont) qout[qi] = pid;
-        emit_ray(sc, cont, nro, nrd, cont ? &b.path_hit[pid] : nullptr, pid, b.q_ext_cam, &b.counts[kCntExtCam + i + 1], nullptr);
+        (void)emit_ray(sc, cont, nro, nrd, cont ? &b.path_hit[pid] : nullptr, pid, b.q_ext_cam,
+                       &b.counts[kCntPad * (kCntExtCam + i + 1)], ap_lds, phase);
         for (int k = 0; k < pp.K; k++) {  // batched shadow rays: one append per slot kind keeps waves converged
             const bool emit = (mask >> k) & 1u;
             const size_t si = emit ? (size_t)pid * pp.K + k : 0;
             const f3 so = emit ? xyz(b.sh_o[si]) : nro, sd = emit ? xyz(b.sh_d[si]) : nrd;
-            emit_ray(sc, emit, so, sd, emit ? &b.sh_hit[si] : nullptr, (int)si, b.q_shadow, &b.counts[kCntShadow + i],
-                     &b.counts[kCntShadowTriv + i]);
+            if (emit_ray(sc, emit, so, sd, emit ? &b.sh_hit[si] : nullptr, (int)si, b.q_shadow,
+                         &b.counts[kCntPad * (kCntShadow + i)], ap_lds, phase))
+                n_trivial++;
         }
     }
+    n_trivial = wave_sum_i(n_trivial);
+    if ((threadIdx.x & 63u) == 0 && n_trivial > 0) atomicAdd(&b.counts[kCntPad * (kCntShadowTriv + i)], n_trivial);
 }
 
 // visibility + accumulation for vertex i (kernel.cu:249-256, 268-279)
 __global__ __launch_bounds__(kBlock) void k_resolve(PassParams pp, WfBuffers b, int i) {
-    const int n = b.counts[kCntCam + i];
+    const int n = b.counts[kCntPad * (kCntCam + i)];
     const int *qin = b.q_cam[i & 1];
     for (int idx = blockIdx.x * kBlock + threadIdx.x; idx < n; idx += gridDim.x * kBlock) {
         const int pid = qin[idx];
@@ -392,10 +442,10 @@ __global__ __launch_bounds__(kBlock) void k_accumulate(PassParams pp, WfBuffers 
 __global__ void k_tally(WfBuffers b, int Dc, int Dl) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     unsigned long long cam = 0, sh = 0, li = 0, ext = 0;
-    for (int i = 0; i < Dc; i++) { cam += (unsigned long long)b.counts[kCntCam + i]; sh += (unsigned long long)b.counts[kCntShadow + i] + (unsigned long long)b.counts[kCntShadowTriv + i]; }
-    for (int i = 0; i < Dl; i++) li += (unsigned long long)b.counts[kCntLight + i];
-    for (int i = 0; i < Dc; i++) ext += (unsigned long long)b.counts[kCntExtCam + i] + (unsigned long long)b.counts[kCntShadow + i];
-    for (int i = 0; i < Dl; i++) ext += (unsigned long long)b.counts[kCntExtLight + i];
+    for (int i = 0; i < Dc; i++) { cam += (unsigned long long)b.counts[kCntPad * (kCntCam + i)]; sh += (unsigned long long)b.counts[kCntPad * (kCntShadow + i)] + (unsigned long long)b.counts[kCntPad * (kCntShadowTriv + i)]; }
+    for (int i = 0; i < Dl; i++) li += (unsigned long long)b.counts[kCntPad * (kCntLight + i)];
+    for (int i = 0; i < Dc; i++) ext += (unsigned long long)b.counts[kCntPad * (kCntExtCam + i)] + (unsigned long long)b.counts[kCntPad * (kCntShadow + i)];
+    for (int i = 0; i < Dl; i++) ext += (unsigned long long)b.counts[kCntPad * (kCntExtLight + i)];
     b.totals[0] += cam;
     b.totals[1] += sh;
     b.totals[2] += li;
@@ -463,7 +513,7 @@ int wavefront_render(const HostScene &hs, DeviceCtx &dc, const mipt_render_confi
     sizes[12] = sizes[13] = P * 4;
     sizes[14] = P * K * 4;
     sizes[25] = P * 4;
-    sizes[17] = kCntTotal * 4 + 64;
+    sizes[17] = (size_t)kCntTotal * kCntPad * 4 + 64;
     if (Dl > 0) {
         sizes[15] = sizes[16] = sizes[26] = P * 4;
         sizes[18] = sizes[19] = sizes[20] = P * Dl * sizeof(f4);
@@ -483,7 +533,7 @@ int wavefront_render(const HostScene &hs, DeviceCtx &dc, const mipt_render_confi
     b.q_light[0] = dc.wf[15].as<int>(); b.q_light[1] = dc.wf[16].as<int>();
     b.q_ext_cam = dc.wf[25].as<int>(); b.q_ext_light = dc.wf[26].as<int>();
     b.counts = dc.wf[17].as<int>();
-    b.totals = reinterpret_cast<unsigned long long *>(dc.wf[17].as<char>() + kCntTotal * 4 + 8);
+    b.totals = reinterpret_cast<unsigned long long *>(dc.wf[17].as<char>() + (size_t)kCntTotal * kCntPad * 4 + 8);
     b.lv_pos = dc.wf[18].as<f4>(); b.lv_nrm = dc.wf[19].as<f4>(); b.lv_T = dc.wf[20].as<f4>();
     b.l_o = dc.wf[21].as<f4>(); b.l_d = dc.wf[22].as<f4>(); b.l_hit = dc.wf[23].as<HitRec>(); b.l_state = dc.wf[24].as<f4>();
 
@@ -500,7 +550,7 @@ int wavefront_render(const HostScene &hs, DeviceCtx &dc, const mipt_render_confi
     auto extend = [&](const f4 *ro, const f4 *rd, const int *queue, const int *count, HitRec *hits, size_t n_max) {
         hipEvent_t a = dc.events.next(), e = dc.events.next();
         (void)hipEventRecord(a, sm);
-        launch_extend(dc, count_mode, ro, rd, queue, count, 0, (int64_t)n_max, hits, &b.counts[kCntWork + (n_launch++)],
+        launch_extend(dc, count_mode, ro, rd, queue, count, 0, (int64_t)n_max, hits, &b.counts[kCntPad * (kCntWork + (n_launch++))],
                       dc.counters.as<unsigned long long>());
         (void)hipEventRecord(e, sm);
         ext_ev.emplace_back(a, e);
@@ -516,20 +566,20 @@ int wavefront_render(const HostScene &hs, DeviceCtx &dc, const mipt_render_confi
         pp.sample0 = cfg.sample_begin + (int)done * stride;
         const size_t np = (size_t)pp.n_slots * npix;
         const unsigned full_grid = (unsigned)((np + kBlock - 1) / kBlock);
-        WF_TRY(hipMemsetAsync(b.counts, 0, kCntTotal * 4, sm));
+        WF_TRY(hipMemsetAsync(b.counts, 0, (size_t)kCntTotal * kCntPad * 4, sm));
         n_launch = 0;
         hipLaunchKernelGGL(k_raygen, dim3(full_grid), dim3(kBlock), 0, sm, dc.view, pp, b);
         if (Dl > 0) {
             hipLaunchKernelGGL(k_lightgen, dim3(full_grid), dim3(kBlock), 0, sm, dc.view, pp, b);
             for (int i = 0; i < Dl; i++) {
-                extend(b.l_o, b.l_d, b.q_ext_light, &b.counts[kCntExtLight + i], b.l_hit, np);
+                extend(b.l_o, b.l_d, b.q_ext_light, &b.counts[kCntPad * (kCntExtLight + i)], b.l_hit, np);
                 hipLaunchKernelGGL(k_light_shade, dim3(path_grid), dim3(kBlock), 0, sm, dc.view, pp, b, i);
             }
         }
         for (int i = 0; i < Dc; i++) {
-            extend(b.path_o, b.path_d, b.q_ext_cam, &b.counts[kCntExtCam + i], b.path_hit, np);
+            extend(b.path_o, b.path_d, b.q_ext_cam, &b.counts[kCntPad * (kCntExtCam + i)], b.path_hit, np);
             hipLaunchKernelGGL(k_shade, dim3(path_grid), dim3(kBlock), 0, sm, dc.view, pp, b, i);
-            extend(b.sh_o, b.sh_d, b.q_shadow, &b.counts[kCntShadow + i], b.sh_hit, np * K);
+            extend(b.sh_o, b.sh_d, b.q_shadow, &b.counts[kCntPad * (kCntShadow + i)], b.sh_hit, np * K);
             hipLaunchKernelGGL(k_resolve, dim3(path_grid), dim3(kBlock), 0, sm, pp, b, i);
             // the shadow queue is refilled from slot 0 by the next vertex: its count lives in its own slot
         }
