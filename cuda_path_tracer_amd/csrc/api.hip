@@ -209,7 +209,8 @@ int mipt_scene_commit(mipt_scene *s, const int *device_ids, int n_devices) {
         HIP_TRY(hipMalloc(&dc.arena, s->host.arena.size()));
         HIP_TRY(hipMemcpyAsync(dc.arena, s->host.arena.data(), s->host.arena.size(), hipMemcpyHostToDevice, dc.stream));
         HIP_TRY(hipStreamSynchronize(dc.stream));
-        HIP_TRY(dc.counters.reserve(128));  // [0,64) traversal counters, [64,128) work cursor of the persistent kernel
+        HIP_TRY(dc.counters.reserve(512));
+        HIP_TRY(hipMemset(dc.counters.p, 0, 512));  // [0,64) traversal counters, [64,128) work cursor of the persistent kernel
         dc.extend_blocks_per_cu = query_extend_blocks_per_cu();
         const char *ev = getenv("MIPT_EXTEND");
         dc.extend_simple = ev && std::string(ev) == "simple";
@@ -237,7 +238,7 @@ int mipt_trace_closest_device(mipt_scene *s, int slot, const float *d_ray_o, con
     dc.events.reset();
     hipEvent_t e0 = dc.events.next(), e1 = dc.events.next(), e2 = dc.events.next(), e3 = dc.events.next();
     const bool count = (flags & MIPT_FLAG_COUNTERS) != 0;
-    HIP_TRY(hipMemsetAsync(dc.counters.p, 0, 128, dc.stream));
+    HIP_TRY(hipMemsetAsync(dc.counters.p, 0, 512, dc.stream));
     const int blocks = (int)((n + 255) / 256);
     HIP_TRY(hipEventRecord(e0, dc.stream));
     hipLaunchKernelGGL(k_make_rays, dim3(blocks), dim3(256), 0, dc.stream, d_ray_o, d_ray_d, n, dc.ray_o.as<f4>(),
@@ -262,6 +263,9 @@ int mipt_trace_closest_device(mipt_scene *s, int slot, const float *d_ray_o, con
         st->ms_other = ms_all - ms_ext;
         if (count) fill_counters(dc, st);
     }
+#ifdef MIPT_PHASE_STATS
+    if (!count) dump_phase_stats(dc, "trace_closest");
+#endif
     return 0;
 }
 

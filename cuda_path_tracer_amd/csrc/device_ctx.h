@@ -1,6 +1,7 @@
 // device_ctx.h -- per-device state of a committed scene (internal to libmipt).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <cstdio>
 #include <string>
 #include <vector>
 #include "scene_host.h"
@@ -75,5 +76,20 @@ struct DeviceCtx {
     DevBuf wf[28];
     EventPool events;
 };
+
+#ifdef MIPT_PHASE_STATS
+// developer build: print and clear the phase table the instrumented extend kernel accumulated (see traverse.h)
+inline void dump_phase_stats(DeviceCtx &dc, const char *what) {
+    static const char *names[12] = {"loop", "finish", "refill", "open_mesh", "scan_entry", "scan_group4", "edge_tests", "pop_iter",
+                                    "descend_entry", "descend_step", "leaf_cull", "-"};
+    unsigned long long v[24];
+    (void)hipMemcpy(v, dc.counters.as<char>() + 128, sizeof(v), hipMemcpyDeviceToHost);
+    (void)hipMemset(dc.counters.as<char>() + 128, 0, sizeof(v));
+    fprintf(stderr, "[phase stats] %s\n", what);
+    for (int i = 0; i < 11; i++)
+        fprintf(stderr, "  %-14s exec %12llu lanes %14llu  util %.3f\n", names[i], v[2 * i], v[2 * i + 1],
+                v[2 * i] ? (double)v[2 * i + 1] / (64.0 * (double)v[2 * i]) : 0.0);
+}
+#endif
 
 }  // namespace mipt

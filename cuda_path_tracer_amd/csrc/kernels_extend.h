@@ -56,6 +56,9 @@ __global__ __launch_bounds__(kExtendBlock, 5) void k_extend(DScene sc, const f4 
     const int lane = (int)(threadIdx.x & 63u);
     TravCounters tc = {0u, 0u, 0u, 0u, 0u};
     unsigned int hit_tris = 0;
+#ifdef MIPT_PHASE_STATS
+    PhaseStats ps = {};
+#endif
 
     bool has_ray = false, exhausted = false;
     bool start_mesh = false;  // lane must open mesh `m`, or store its result when m == n_meshes
@@ -86,9 +89,11 @@ __global__ __launch_bounds__(kExtendBlock, 5) void k_extend(DScene sc, const f4 
     };
 
     for (;;) {
+        PSTAT(ps, 0);
         // ---- rays that ran out of meshes: Scene::firstIntersect's result (kernel.cu:145-160) ------------------
         if (has_ray && start_mesh && m >= sc.n_meshes) {
             // spheres/planes were evaluated at fetch time; a mesh hit wins ties because meshes come first
+            PSTAT(ps, 1);
             const bool mesh_wins = (best > 0.0f) && (q_t < 0.0f || best <= q_t);
             HitRec h;
             h.t = mesh_wins ? best : q_t;
@@ -110,6 +115,7 @@ __global__ __launch_bounds__(kExtendBlock, 5) void k_extend(DScene sc, const f4 
                 const int rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned int)(idle >> 32),
                                                                 __builtin_amdgcn_mbcnt_lo((unsigned int)idle, 0u));
                 if (!has_ray && base + rank < n) {
+                    PSTAT(ps, 2);
                     slot = queue ? queue[base + rank] : base + rank;
                     const f4 o4 = ray_o[slot], d4 = ray_d[slot];
                     o = mk3(o4.x, o4.y, o4.z);
@@ -143,6 +149,7 @@ __global__ __launch_bounds__(kExtendBlock, 5) void k_extend(DScene sc, const f4 
         }
         // ---- open the next mesh: root box test (mesh.cuh:254) -------------------------------------------------
         if (has_ray && start_mesh && m < sc.n_meshes) {
+            PSTAT(ps, 3);
             node = sc.meshes[m].root;
             nd = sc.nodes[node];
             load_slab(sc, node, o, d, cur);
@@ -163,7 +170,8 @@ __global__ __launch_bounds__(kExtendBlock, 5) void k_extend(DScene sc, const f4 
                 if (pending) {
                     float bt;
                     int bi;
-                    leaf_scan(sc, (int)nd.a, (int)(nd.b & kIdxMask), o, d, cur, bt, bi);
+                    PSTAT(ps, 4);
+                    leaf_scan(sc, (int)nd.a, (int)(nd.b & kIdxMask), o, d, cur, bt, bi PSTAT_PASS);
                     pending = false;
                     after_leaf(bt, bi);
                 }
@@ -174,6 +182,7 @@ __global__ __launch_bounds__(kExtendBlock, 5) void k_extend(DScene sc, const f4 
         // is dropped without being walked -- the continuation is the same as after walking it in vain.  (The
         // counting variant walks everything so that its counters stay those of the reference traversal.)
         while (need_pop) {
+            PSTAT(ps, 7);
             sp--;
             node = stk.pop(sp);
             if (!COUNT && leaf_culled(sc, node, o, d)) {
@@ -192,13 +201,15 @@ __global__ __launch_bounds__(kExtendBlock, 5) void k_extend(DScene sc, const f4 
         if (!has_ray || pending || start_mesh) continue;
 
         // ---- walk down (at most step_cap steps per round), then the leaf visit ---------------------------------
-        const bool sub_culled = descend_to_leaf<LdsStack, COUNT, !COUNT>(sc, o, d, cur, node, nd, sp, stk, tc, tune.step_cap);
+        PSTAT(ps, 8);
+        const bool sub_culled = descend_to_leaf<LdsStack, COUNT, !COUNT>(sc, o, d, cur, node, nd, sp, stk, tc, tune.step_cap PSTAT_PASS);
         if (sub_culled) {  // the subtree just entered cannot contain a hit: same continuation as a fruitless visit
             after_leaf(-1.0f, -1);
             continue;
         }
         if ((nd.b >> 30) != 3u) continue;  // out of steps for this round: keep walking next round
         if (COUNT) { tc.refs += nd.b & kIdxMask; tc.tris += nd.b & kIdxMask; }
+        PSTAT(ps, 10);
         if (!leaf_culled(sc, node, o, d)) {
             pending = true;  // scanned later, together with other lanes' leaves
         } else {
@@ -207,6 +218,17 @@ __global__ __launch_bounds__(kExtendBlock, 5) void k_extend(DScene sc, const f4 
         }
     }
     if (COUNT) flush_counters(tc, hit_tris, ctr);
+#ifdef MIPT_PHASE_STATS
+    if (!COUNT) {  // ctr + 16: after the traversal counters and the work cursor (see api.hip)
+        for (int i = 0; i < kPhases; i++) {
+            const unsigned int e = wave_sum(ps.exec[i]), l = wave_sum(ps.lanes[i]);
+            if (lane == 0) {
+                atomicAdd(&ctr[16 + 2 * i], (unsigned long long)e);
+                atomicAdd(&ctr[16 + 2 * i + 1], (unsigned long long)l);
+            }
+        }
+    }
+#endif
 }
 
 // Reference formulation (one ray start to finish per lane, grid-stride): kept for A/B timing of the

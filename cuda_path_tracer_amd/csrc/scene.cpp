@@ -322,6 +322,7 @@ bool HostScene::pack(int n_threads, std::string &err) {
     L.tight = section((size_t)total_nodes * 32);
     L.refs = section((size_t)total_refs * 4);
     L.leaf_planes = section((size_t)total_refs * 16);
+    L.leaf_spheres = section((size_t)total_refs * 16);
     L.tri_pos = section((size_t)total_tris * 48);
     L.tri_nrm = section((size_t)total_tris * 48);
     L.meshes = section(meshes.size() * sizeof(DMesh));
@@ -393,6 +394,90 @@ bool HostScene::pack(int n_threads, std::string &err) {
             lp[4 * i] = N.x; lp[4 * i + 1] = N.y; lp[4 * i + 2] = N.z;
             lp[4 * i + 3] = -dot3(N, a);
         }
+        // leaf-ordered candidate spheres (no counterpart in the reference; they change no result): a hit the leaf
+        // loop accepts lies on the triangle (up to the rounding of the edge tests) and inside the leaf box (up to its
+        // 1e-5 slack), i.e. inside both the triangle's smallest enclosing sphere and the sphere around
+        // AABB(triangle) ∩ cull box of the leaf.  The smaller of the two, grown by 2^-10 relative + 2^-13 x (largest
+        // coordinate, at least 1) absolute, is what leaf_scan() tests the ray against before it evaluates a candidate.
+        float *ls = reinterpret_cast<float *>(A + L.leaf_spheres) + (size_t)hm.ref_base * 4;
+        for (int64_t i = 0; i < hm.n_nodes; i++) {
+            const KdNode k = t.nodes[(size_t)i];
+            if ((k.b >> 30) != 3u) continue;
+            const float *tb = tight + 8 * i;
+            const int cnt = (int)(k.b & kIdxMask);
+            for (int r = 0; r < cnt; r++) {
+                const size_t ri = (size_t)k.a + r;
+                const float *v = hm.pos.data() + (size_t)t.refs[ri] * 9;
+                double P[3][3], mag = 1.0;
+                for (int q = 0; q < 3; q++)
+                    for (int c = 0; c < 3; c++) { P[q][c] = v[3 * q + c]; mag = std::max(mag, std::fabs(P[q][c])); }
+                auto dist2 = [](const double *x, const double *y) {
+                    return (x[0] - y[0]) * (x[0] - y[0]) + (x[1] - y[1]) * (x[1] - y[1]) + (x[2] - y[2]) * (x[2] - y[2]);
+                };
+                // smallest enclosing sphere of the triangle: around the longest edge if the opposite vertex fits, else
+                // the circumscribed one (acute triangle)
+                double cen[3], rad2;
+                {
+                    int e0 = 0, e1 = 1, eo = 2;
+                    double best = dist2(P[0], P[1]);
+                    if (dist2(P[1], P[2]) > best) { best = dist2(P[1], P[2]); e0 = 1; e1 = 2; eo = 0; }
+                    if (dist2(P[2], P[0]) > best) { best = dist2(P[2], P[0]); e0 = 2; e1 = 0; eo = 1; }
+                    for (int c = 0; c < 3; c++) cen[c] = 0.5 * (P[e0][c] + P[e1][c]);
+                    rad2 = 0.25 * best;
+                    if (dist2(cen, P[eo]) > rad2) {
+                        const double *a = P[0], *b = P[1], *c = P[2];
+                        double ab[3], ac[3], n[3];
+                        for (int q = 0; q < 3; q++) { ab[q] = b[q] - a[q]; ac[q] = c[q] - a[q]; }
+                        n[0] = ab[1] * ac[2] - ab[2] * ac[1]; n[1] = ab[2] * ac[0] - ab[0] * ac[2]; n[2] = ab[0] * ac[1] - ab[1] * ac[0];
+                        const double n2 = n[0] * n[0] + n[1] * n[1] + n[2] * n[2];
+                        const double ab2 = ab[0] * ab[0] + ab[1] * ab[1] + ab[2] * ab[2], ac2 = ac[0] * ac[0] + ac[1] * ac[1] + ac[2] * ac[2];
+                        if (n2 > 0.0) {
+                            // circumcentre = a + (|ac|^2 (n x ab) + |ab|^2 (ac x n)) / (2 |n|^2)
+                            double u[3], w[3];
+                            u[0] = n[1] * ab[2] - n[2] * ab[1]; u[1] = n[2] * ab[0] - n[0] * ab[2]; u[2] = n[0] * ab[1] - n[1] * ab[0];  // n x ab
+                            w[0] = ac[1] * n[2] - ac[2] * n[1]; w[1] = ac[2] * n[0] - ac[0] * n[2]; w[2] = ac[0] * n[1] - ac[1] * n[0];  // ac x n
+                            double cc[3];
+                            for (int q = 0; q < 3; q++) cc[q] = a[q] + (ac2 * u[q] + ab2 * w[q]) / (2.0 * n2);
+                            const double r2 = std::max(dist2(cc, a), std::max(dist2(cc, b), dist2(cc, c)));
+                            if (r2 <= 2.0 * rad2) {  // an acute triangle's circumradius^2 is <= 4/3 of (longest edge / 2)^2
+                                for (int q = 0; q < 3; q++) cen[q] = cc[q];
+                                rad2 = r2;
+                            } else {
+                                rad2 = std::max(rad2, dist2(cen, P[eo]));
+                            }
+                        } else {
+                            rad2 = std::max(rad2, dist2(cen, P[eo]));
+                        }
+                    }
+                }
+                // sphere around AABB(triangle) ∩ leaf cull box (good for triangles much larger than their leaf)
+                {
+                    double lo[3], hi[3];
+                    bool empty = false;
+                    for (int c = 0; c < 3; c++) {
+                        lo[c] = std::max((double)tb[2 * c], std::min(P[0][c], std::min(P[1][c], P[2][c])));
+                        hi[c] = std::min((double)tb[2 * c + 1], std::max(P[0][c], std::max(P[1][c], P[2][c])));
+                        mag = std::max(mag, std::max(std::fabs((double)tb[2 * c]), std::fabs((double)tb[2 * c + 1])));
+                        if (!(lo[c] <= hi[c])) empty = true;
+                    }
+                    if (!empty) {
+                        double bc[3], br2 = 0.0;
+                        for (int c = 0; c < 3; c++) { bc[c] = 0.5 * (lo[c] + hi[c]); br2 += 0.25 * (hi[c] - lo[c]) * (hi[c] - lo[c]); }
+                        if (br2 < rad2) { rad2 = br2; for (int c = 0; c < 3; c++) cen[c] = bc[c]; }
+                    }
+                }
+                if (!std::isfinite(mag)) mag = 1.0;
+                const double R = std::sqrt(rad2) * (1.0 + 1.0 / 1024.0) + mag / 8192.0;
+                float R2 = (float)(R * R);
+                R2 = std::nextafter(R2, INFINITY);
+                if (!(R2 >= 0.0f) || !std::isfinite(R2) || !std::isfinite(cen[0]) || !std::isfinite(cen[1]) || !std::isfinite(cen[2])) {
+                    cen[0] = cen[1] = cen[2] = 0.0;  // non-finite input: never reject (centre 0, infinite radius)
+                    R2 = INFINITY;
+                }
+                ls[4 * ri] = (float)cen[0]; ls[4 * ri + 1] = (float)cen[1]; ls[4 * ri + 2] = (float)cen[2];
+                ls[4 * ri + 3] = R2;
+            }
+        }
         float *tp = reinterpret_cast<float *>(A + L.tri_pos) + (size_t)hm.tri_base * 12;
         float *tn = reinterpret_cast<float *>(A + L.tri_nrm) + (size_t)hm.tri_base * 12;
         for (int64_t i = 0; i < hm.n_tris * 3; i++) {
@@ -449,6 +534,7 @@ DScene HostScene::view(const void *base_v) const {
     d.tight = reinterpret_cast<const f4 *>(base + layout.tight);
     d.refs = reinterpret_cast<const int32_t *>(base + layout.refs);
     d.leaf_planes = reinterpret_cast<const f4 *>(base + layout.leaf_planes);
+    d.leaf_spheres = reinterpret_cast<const f4 *>(base + layout.leaf_spheres);
     d.tri_pos = reinterpret_cast<const f4 *>(base + layout.tri_pos);
     d.tri_nrm = reinterpret_cast<const f4 *>(base + layout.tri_nrm);
     d.meshes = reinterpret_cast<const DMesh *>(base + layout.meshes);

@@ -56,6 +56,7 @@ struct DScene {
     const f4 *tight;        // per node, same layout as boxes: leaf cull box (triangle AABB within the leaf box)
     const int32_t *refs;
     const f4 *leaf_planes;  // per leaf reference: (N.xyz, -dot(N,a)) of that triangle, in leaf order
+    const f4 *leaf_spheres; // per leaf reference: (centre, radius^2) of a sphere that contains every acceptable hit point
     const f4 *tri_pos;
     const f4 *tri_nrm;
     const DMesh *meshes;

@@ -26,6 +26,26 @@ struct TravCounters {
     unsigned int culled;                   // candidates of those that the leaf cull skipped
 };
 
+// Developer build only (make PHASE_STATS=1): per-phase SIMD-lane use of the persistent extend kernel.
+// exec[i] counts wave-level executions of phase i, lanes[i] the lanes active in them.
+#ifdef MIPT_PHASE_STATS
+constexpr int kPhases = 12;
+struct PhaseStats { unsigned int exec[kPhases], lanes[kPhases]; };
+#define PSTAT(ps, i)                                                                                     \
+    do {                                                                                                 \
+        (ps).lanes[i]++;                                                                                 \
+        if ((int)(threadIdx.x & 63u) == __ffsll((long long)__ballot(1)) - 1) (ps).exec[i]++;             \
+    } while (0)
+#define PSTAT_ARG , PhaseStats &ps
+#define PSTAT_PASS , ps
+#define PSTAT_LOCAL PhaseStats ps = {};
+#else
+#define PSTAT(ps, i)
+#define PSTAT_ARG
+#define PSTAT_PASS
+#define PSTAT_LOCAL
+#endif
+
 PT_HD float as_f32(uint32_t u) {
     union { uint32_t u; float f; } c;
     c.u = u;
@@ -114,8 +134,9 @@ PT_HD bool leaf_culled(const DScene &sc, int node, f3 o, f3 d);
 // ray misses the cull box of the subtree it just stepped into (see leaf_culled): nothing can be found below.
 template <class Stack, bool COUNT, bool CULL = false>
 PT_HD bool descend_to_leaf(const DScene &sc, f3 o, f3 d, SlabBox &cur, int &node, KdNode &nd, int &sp, Stack &stk,
-                           TravCounters &ctr, int max_steps = 1 << 30) {
+                           TravCounters &ctr, int max_steps PSTAT_ARG) {
     for (int step = 0; (nd.b >> 30) != 3u && step < max_steps; step++) {
+        PSTAT(ps, 9);
         const uint32_t ax = nd.b >> 30;
         const int left = (int)(nd.b & kIdxMask), right = left + 1;
         const KdNodePair pair = *reinterpret_cast<const KdNodePair *>(sc.nodes + left);
@@ -157,9 +178,7 @@ PT_HD bool descend_to_leaf(const DScene &sc, f3 o, f3 d, SlabBox &cur, int &node
     return false;
 }
 
-// Leaf loop of Mesh::intersect (mesh.cuh:290-299).  The 16-byte plane records of a leaf are contiguous: four
-// are fetched ahead of use (indices clamped, so every load is in bounds) and evaluated in leaf order -- the
-// sequential "t < best" rule keeps the earliest of equal hits.
+// Leaf loop of Mesh::intersect (mesh.cuh:290-299): leaf_culled() first, then leaf_scan().
 //
 // Leaf cull (no counterpart in the reference; it changes no result): an accepted hit point lies on a triangle of
 // the leaf and inside the leaf box, hence inside sc.tight[node] = AABB(leaf triangles) ∩ leaf box.  The ray is
@@ -189,7 +208,7 @@ PT_HD bool leaf_culled(const DScene &sc, int node, f3 o, f3 d) {
     return out | (tn > tf + 2.44140625e-4f * (fabsf(tf) + 1.0f)) | !(lo[0] <= hi[0]);
 }
 
-PT_HD void leaf_scan(const DScene &sc, int first, int count, f3 o, f3 d, const SlabBox &cur, float &bt, int &bi);
+PT_HD void leaf_scan(const DScene &sc, int first, int count, f3 o, f3 d, const SlabBox &cur, float &bt, int &bi PSTAT_ARG);
 
 template <bool COUNT>
 PT_HD void leaf_closest(const DScene &sc, int node, KdNode nd, f3 o, f3 d, const SlabBox &cur, float &bt, int &bi,
@@ -202,24 +221,51 @@ PT_HD void leaf_closest(const DScene &sc, int node, KdNode nd, f3 o, f3 d, const
         if (COUNT) ctr.culled += count;
         return;
     }
-    leaf_scan(sc, (int)nd.a, count, o, d, cur, bt, bi);
+    PSTAT_LOCAL
+    leaf_scan(sc, (int)nd.a, count, o, d, cur, bt, bi PSTAT_PASS);
 }
 
-// The candidate loop proper: `count` plane records starting at reference `first`, leaf box in `cur`.
-PT_HD void leaf_scan(const DScene &sc, int first, int count, f3 o, f3 d, const SlabBox &cur, float &bt, int &bi) {
+// Candidate pre-test (no counterpart in the reference; it changes no result).  sph = (centre, R^2) from the packer
+// contains every hit point this leaf could accept for this triangle, with a margin far above any rounding in play
+// (scene.cpp).  A ray whose LINE passes the centre at more than R cannot produce one.  |d| <= 1 by the Ray
+// constructor rule (ray.cuh:10), so |(c-o) x d| underestimates the distance -- the safe side; the 2^-26 |c-o|^2 term
+// covers the rounding of the cross product (and of P = o + d t in the reference) for origins far from the triangle.
+PT_HD bool candidate_sphere_hit(f4 sph, f3 o, f3 d) {
+    const f3 co = mk3(sph.x, sph.y, sph.z) - o;
+    const f3 q = cross3(co, d);
+    return dot3(q, q) <= sph.w + 1.4901161e-8f * dot3(co, co);
+}
+
+// The candidate loop proper: `count` references starting at `first`, leaf box in `cur`.  Two passes per 32
+// candidates.  Pass 1 streams the leaf's contiguous 16-byte spheres (four fetched ahead of use, indices clamped so
+// every load is in bounds) and marks the candidates whose sphere the ray passes -- a few per leaf.  Pass 2 gives the
+// marked ones the reference's evaluation, in leaf order (the sequential "t < best" rule keeps the earliest of
+// equal hits); the lanes of a wave run it together instead of each branching out of pass 1 on its own.
+PT_HD void leaf_scan(const DScene &sc, int first, int count, f3 o, f3 d, const SlabBox &cur, float &bt, int &bi PSTAT_ARG) {
     bt = -1.0f;
     bi = -1;
-    for (int i0 = 0; i0 < count; i0 += 4) {
-        f4 pl[4];
+    for (int c0 = 0; c0 < count; c0 += 32) {
+        const int c1 = (count - c0 < 32) ? count - c0 : 32;
+        uint32_t marked = 0u;
+        for (int i0 = 0; i0 < c1; i0 += 4) {
+            PSTAT(ps, 5);
+            f4 sp[4];
 #pragma unroll
-        for (int k = 0; k < 4; k++) pl[k] = sc.leaf_planes[first + ((i0 + k < count) ? i0 + k : count - 1)];
+            for (int k = 0; k < 4; k++) sp[k] = sc.leaf_spheres[first + c0 + ((i0 + k < c1) ? i0 + k : c1 - 1)];
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const float t = (i0 + k < count) ? plane_candidate(pl[k], o, d, cur, bt) : -1.0f;
+            for (int k = 0; k < 4; k++)
+                marked |= ((i0 + k < c1) && candidate_sphere_hit(sp[k], o, d)) ? (1u << (i0 + k)) : 0u;
+        }
+        while (marked != 0u) {
+            PSTAT(ps, 6);
+            const int r = first + c0 + (__builtin_ffs((int)marked) - 1);
+            marked &= marked - 1u;
+            const f4 pl = sc.leaf_planes[r];
+            const float t = plane_candidate(pl, o, d, cur, bt);
             if (t > 0.0f) {
-                const int tri = sc.refs[first + i0 + k];
+                const int tri = sc.refs[r];
                 const f4 pa = sc.tri_pos[3 * (size_t)tri], pb = sc.tri_pos[3 * (size_t)tri + 1], pc = sc.tri_pos[3 * (size_t)tri + 2];
-                if (inside_triangle(pl[k], mk3(pa.x, pa.y, pa.z), mk3(pb.x, pb.y, pb.z), mk3(pc.x, pc.y, pc.z), o, d, t)) {
+                if (inside_triangle(pl, mk3(pa.x, pa.y, pa.z), mk3(pb.x, pb.y, pb.z), mk3(pc.x, pc.y, pc.z), o, d, t)) {
                     bt = t;
                     bi = tri;
                 }
@@ -242,7 +288,8 @@ PT_HD void mesh_closest(const DScene &sc, int root, f3 o, f3 d, Stack &stk, floa
     if (COUNT) { ctr.pops++; ctr.nodes++; }
     KdNode leaf = sc.nodes[node];
     for (;;) {
-        descend_to_leaf<Stack, COUNT>(sc, o, d, cur, node, leaf, sp, stk, ctr);
+        PSTAT_LOCAL
+        descend_to_leaf<Stack, COUNT>(sc, o, d, cur, node, leaf, sp, stk, ctr, 1 << 30 PSTAT_PASS);
         float bt;
         int bi;
         leaf_closest<COUNT>(sc, node, leaf, o, d, cur, bt, bi, ctr);

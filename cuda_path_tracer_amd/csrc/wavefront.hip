@@ -589,6 +589,9 @@ int wavefront_render(const HostScene &hs, DeviceCtx &dc, const mipt_render_confi
     }
     WF_TRY(hipEventRecord(ev_end, sm));
     WF_TRY(hipStreamSynchronize(sm));
+#ifdef MIPT_PHASE_STATS
+    if (!count_mode) dump_phase_stats(dc, "render");
+#endif
     if (st) {
         unsigned long long tot[4] = {0, 0, 0, 0};
         WF_TRY(hipMemcpy(tot, b.totals, sizeof(tot), hipMemcpyDeviceToHost));
