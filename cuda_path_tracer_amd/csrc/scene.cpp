@@ -322,7 +322,7 @@ bool HostScene::pack(int n_threads, std::string &err) {
     L.tight = section((size_t)total_nodes * 32);
     L.refs = section((size_t)total_refs * 4);
     L.leaf_planes = section((size_t)total_refs * 16);
-    L.leaf_spheres = section((size_t)total_refs * 16);
+    L.leaf_spheres = section(((size_t)total_refs / 2 + 4) * sizeof(SpherePair));  // + padding the scan may over-read
     L.tri_pos = section((size_t)total_tris * 48);
     L.tri_nrm = section((size_t)total_tris * 48);
     L.meshes = section(meshes.size() * sizeof(DMesh));
@@ -335,6 +335,11 @@ bool HostScene::pack(int n_threads, std::string &err) {
     L.total = off;
     arena.assign(L.total, 0);
     uint8_t *A = arena.data();
+    {  // slots no reference owns (padding) must never pass: R^2 = -inf
+        float *ls = reinterpret_cast<float *>(A + L.leaf_spheres);
+        const size_t n_pairs = (size_t)total_refs / 2 + 4;
+        for (size_t i = 0; i < n_pairs; i++) ls[8 * i + 6] = ls[8 * i + 7] = -INFINITY;
+    }
     for (size_t m = 0; m < meshes.size(); m++) {
         const HostMesh &hm = meshes[m];
         const KdTree &t = trees[m];
@@ -399,7 +404,7 @@ bool HostScene::pack(int n_threads, std::string &err) {
         // 1e-5 slack), i.e. inside both the triangle's smallest enclosing sphere and the sphere around
         // AABB(triangle) ∩ cull box of the leaf.  The smaller of the two, grown by 2^-10 relative + 2^-13 x (largest
         // coordinate, at least 1) absolute, is what leaf_scan() tests the ray against before it evaluates a candidate.
-        float *ls = reinterpret_cast<float *>(A + L.leaf_spheres) + (size_t)hm.ref_base * 4;
+        float *ls = reinterpret_cast<float *>(A + L.leaf_spheres);  // indexed by GLOBAL reference (pairs interleaved)
         for (int64_t i = 0; i < hm.n_nodes; i++) {
             const KdNode k = t.nodes[(size_t)i];
             if ((k.b >> 30) != 3u) continue;
@@ -407,6 +412,7 @@ bool HostScene::pack(int n_threads, std::string &err) {
             const int cnt = (int)(k.b & kIdxMask);
             for (int r = 0; r < cnt; r++) {
                 const size_t ri = (size_t)k.a + r;
+                const size_t gi = (size_t)hm.ref_base + ri;
                 const float *v = hm.pos.data() + (size_t)t.refs[ri] * 9;
                 double P[3][3], mag = 1.0;
                 for (int q = 0; q < 3; q++)
@@ -474,8 +480,9 @@ bool HostScene::pack(int n_threads, std::string &err) {
                     cen[0] = cen[1] = cen[2] = 0.0;  // non-finite input: never reject (centre 0, infinite radius)
                     R2 = INFINITY;
                 }
-                ls[4 * ri] = (float)cen[0]; ls[4 * ri + 1] = (float)cen[1]; ls[4 * ri + 2] = (float)cen[2];
-                ls[4 * ri + 3] = R2;
+                float *rec = ls + 8 * (gi >> 1) + (gi & 1);
+                rec[0] = (float)cen[0]; rec[2] = (float)cen[1]; rec[4] = (float)cen[2];
+                rec[6] = R2;
             }
         }
         float *tp = reinterpret_cast<float *>(A + L.tri_pos) + (size_t)hm.tri_base * 12;
@@ -534,7 +541,7 @@ DScene HostScene::view(const void *base_v) const {
     d.tight = reinterpret_cast<const f4 *>(base + layout.tight);
     d.refs = reinterpret_cast<const int32_t *>(base + layout.refs);
     d.leaf_planes = reinterpret_cast<const f4 *>(base + layout.leaf_planes);
-    d.leaf_spheres = reinterpret_cast<const f4 *>(base + layout.leaf_spheres);
+    d.leaf_spheres = reinterpret_cast<const SpherePair *>(base + layout.leaf_spheres);
     d.tri_pos = reinterpret_cast<const f4 *>(base + layout.tri_pos);
     d.tri_nrm = reinterpret_cast<const f4 *>(base + layout.tri_nrm);
     d.meshes = reinterpret_cast<const DMesh *>(base + layout.meshes);

@@ -45,8 +45,15 @@ struct DMesh {
     int32_t material;
 };
 
-struct f4 {
+struct alignas(16) f4 {
     float x, y, z, w;
+};
+
+// Candidate spheres of leaf references 2j and 2j+1, component-interleaved so that one packed fp32 instruction
+// (v_pk_*_f32) works on both candidates: (x0,x1) (y0,y1) (z0,z1) (R0^2,R1^2).
+typedef float v2f __attribute__((ext_vector_type(2)));
+struct alignas(32) SpherePair {
+    v2f x, y, z, r2;
 };
 
 // Device view of the packed scene; passed to kernels by value (kernarg -> scalar loads).
@@ -56,7 +63,8 @@ struct DScene {
     const f4 *tight;        // per node, same layout as boxes: leaf cull box (triangle AABB within the leaf box)
     const int32_t *refs;
     const f4 *leaf_planes;  // per leaf reference: (N.xyz, -dot(N,a)) of that triangle, in leaf order
-    const f4 *leaf_spheres; // per leaf reference: (centre, radius^2) of a sphere that contains every acceptable hit point
+    const SpherePair *leaf_spheres;  // per PAIR of leaf references (global reference index >> 1): spheres that contain
+                                     // every hit point the leaf loop could accept for that reference
     const f4 *tri_pos;
     const f4 *tri_nrm;
     const DMesh *meshes;

@@ -225,40 +225,49 @@ PT_HD void leaf_closest(const DScene &sc, int node, KdNode nd, f3 o, f3 d, const
     leaf_scan(sc, (int)nd.a, count, o, d, cur, bt, bi PSTAT_PASS);
 }
 
-// Candidate pre-test (no counterpart in the reference; it changes no result).  sph = (centre, R^2) from the packer
-// contains every hit point this leaf could accept for this triangle, with a margin far above any rounding in play
-// (scene.cpp).  A ray whose LINE passes the centre at more than R cannot produce one.  |d| <= 1 by the Ray
-// constructor rule (ray.cuh:10), so |(c-o) x d| underestimates the distance -- the safe side; the 2^-26 |c-o|^2 term
-// covers the rounding of the cross product (and of P = o + d t in the reference) for origins far from the triangle.
-PT_HD bool candidate_sphere_hit(f4 sph, f3 o, f3 d) {
-    const f3 co = mk3(sph.x, sph.y, sph.z) - o;
-    const f3 q = cross3(co, d);
-    return dot3(q, q) <= sph.w + 1.4901161e-8f * dot3(co, co);
+// Candidate pre-test (no counterpart in the reference; it changes no result).  A SpherePair holds, for two
+// consecutive leaf references, a sphere (centre, R^2) that contains every hit point the leaf loop could accept for
+// that triangle, with a margin far above any rounding in play (scene.cpp).  A ray whose LINE passes the centre at
+// more than R cannot produce one.  |d| <= 1 by the Ray constructor rule (ray.cuh:10), so |(c-o) x d| underestimates
+// the distance -- the safe side; the 2^-26 |c-o|^2 term covers the rounding of the cross product (and of
+// P = o + d t in the reference) for origins far from the triangle.  Both candidates go through the same packed
+// fp32 instructions (fused multiply-adds are fine here: the test only has to be conservative).
+PT_HD v2f vfma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
+PT_HD uint32_t sphere_pair_hit(const SpherePair s, f3 o, f3 d) {
+    const v2f cx = s.x - o.x, cy = s.y - o.y, cz = s.z - o.z;
+    const v2f qx = vfma(cy, (v2f)(d.z), -(cz * d.y));
+    const v2f qy = vfma(cz, (v2f)(d.x), -(cx * d.z));
+    const v2f qz = vfma(cx, (v2f)(d.y), -(cy * d.x));
+    const v2f q2 = vfma(qz, qz, vfma(qy, qy, qx * qx));
+    const v2f D2 = vfma(cz, cz, vfma(cy, cy, cx * cx));
+    const v2f thr = vfma(D2, (v2f)(1.4901161e-8f), s.r2);
+    return (q2.x <= thr.x ? 1u : 0u) | (q2.y <= thr.y ? 2u : 0u);
 }
 
-// The candidate loop proper: `count` references starting at `first`, leaf box in `cur`.  Two passes per 32
-// candidates.  Pass 1 streams the leaf's contiguous 16-byte spheres (four fetched ahead of use, indices clamped so
-// every load is in bounds) and marks the candidates whose sphere the ray passes -- a few per leaf.  Pass 2 gives the
-// marked ones the reference's evaluation, in leaf order (the sequential "t < best" rule keeps the earliest of
-// equal hits); the lanes of a wave run it together instead of each branching out of pass 1 on its own.
+// The candidate loop proper: `count` references starting at global reference `first`, leaf box in `cur`.  Two
+// passes per 32 references.  Pass 1 streams the sphere pairs (two 32-byte records = four candidates per step; pairs
+// are indexed by global reference >> 1, so the first/last pair may straddle a neighbouring leaf -- those bits are
+// masked off, and the array is padded so every load is in bounds) and marks the candidates whose sphere the ray
+// passes: a few per leaf.  Pass 2 gives the marked ones the reference's evaluation in leaf order (the sequential
+// "t < best" rule keeps the earliest of equal hits); the lanes of a wave run it together instead of each branching
+// out of pass 1 on its own.
 PT_HD void leaf_scan(const DScene &sc, int first, int count, f3 o, f3 d, const SlabBox &cur, float &bt, int &bi PSTAT_ARG) {
     bt = -1.0f;
     bi = -1;
-    for (int c0 = 0; c0 < count; c0 += 32) {
-        const int c1 = (count - c0 < 32) ? count - c0 : 32;
+    const int end = first + count;
+    for (int base = first & ~1; base < end; base += 32) {
+        const int stop = (end - base < 32) ? end - base : 32;  // bits [max(first-base,0), stop) belong to this leaf
+        const SpherePair *sp = sc.leaf_spheres + (base >> 1);
         uint32_t marked = 0u;
-        for (int i0 = 0; i0 < c1; i0 += 4) {
+        for (int p = 0; 2 * p < stop; p += 2) {
             PSTAT(ps, 5);
-            f4 sp[4];
-#pragma unroll
-            for (int k = 0; k < 4; k++) sp[k] = sc.leaf_spheres[first + c0 + ((i0 + k < c1) ? i0 + k : c1 - 1)];
-#pragma unroll
-            for (int k = 0; k < 4; k++)
-                marked |= ((i0 + k < c1) && candidate_sphere_hit(sp[k], o, d)) ? (1u << (i0 + k)) : 0u;
+            const SpherePair s0 = sp[p], s1 = sp[p + 1];
+            marked |= (sphere_pair_hit(s0, o, d) | (sphere_pair_hit(s1, o, d) << 2)) << (2 * p);
         }
+        marked &= (stop < 32 ? (1u << stop) - 1u : 0xffffffffu) & ~((1u << (first > base ? first - base : 0)) - 1u);
         while (marked != 0u) {
             PSTAT(ps, 6);
-            const int r = first + c0 + (__builtin_ffs((int)marked) - 1);
+            const int r = base + (__builtin_ffs((int)marked) - 1);
             marked &= marked - 1u;
             const f4 pl = sc.leaf_planes[r];
             const float t = plane_candidate(pl, o, d, cur, bt);
