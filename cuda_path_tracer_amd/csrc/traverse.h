@@ -245,7 +245,7 @@ PT_HD uint32_t sphere_pair_hit(const SpherePair s, f3 o, f3 d) {
 }
 
 // The candidate loop proper: `count` references starting at global reference `first`, leaf box in `cur`.  Two
-// passes per 32 references.  Pass 1 streams the sphere pairs (two 32-byte records = four candidates per step; pairs
+// passes per 64 references.  Pass 1 streams the sphere pairs (two 32-byte records = four candidates per step; pairs
 // are indexed by global reference >> 1, so the first/last pair may straddle a neighbouring leaf -- those bits are
 // masked off, and the array is padded so every load is in bounds) and marks the candidates whose sphere the ray
 // passes: a few per leaf.  Pass 2 gives the marked ones the reference's evaluation in leaf order (the sequential
@@ -255,20 +255,20 @@ PT_HD void leaf_scan(const DScene &sc, int first, int count, f3 o, f3 d, const S
     bt = -1.0f;
     bi = -1;
     const int end = first + count;
-    for (int base = first & ~1; base < end; base += 32) {
-        const int stop = (end - base < 32) ? end - base : 32;  // bits [max(first-base,0), stop) belong to this leaf
+    for (int base = first & ~1; base < end; base += 64) {
+        const int stop = (end - base < 64) ? end - base : 64;  // bits [max(first-base,0), stop) belong to this leaf
         const SpherePair *sp = sc.leaf_spheres + (base >> 1);
-        uint32_t marked = 0u;
+        unsigned long long marked = 0ull;
         for (int p = 0; 2 * p < stop; p += 2) {
             PSTAT(ps, 5);
             const SpherePair s0 = sp[p], s1 = sp[p + 1];
-            marked |= (sphere_pair_hit(s0, o, d) | (sphere_pair_hit(s1, o, d) << 2)) << (2 * p);
+            marked |= (unsigned long long)(sphere_pair_hit(s0, o, d) | (sphere_pair_hit(s1, o, d) << 2)) << (2 * p);
         }
-        marked &= (stop < 32 ? (1u << stop) - 1u : 0xffffffffu) & ~((1u << (first > base ? first - base : 0)) - 1u);
-        while (marked != 0u) {
+        marked &= (stop < 64 ? (1ull << stop) - 1ull : ~0ull) & ~((1ull << (first > base ? first - base : 0)) - 1ull);
+        while (marked != 0ull) {
             PSTAT(ps, 6);
-            const int r = base + (__builtin_ffs((int)marked) - 1);
-            marked &= marked - 1u;
+            const int r = base + (__builtin_ffsll((long long)marked) - 1);
+            marked &= marked - 1ull;
             const f4 pl = sc.leaf_planes[r];
             const float t = plane_candidate(pl, o, d, cur, bt);
             if (t > 0.0f) {
