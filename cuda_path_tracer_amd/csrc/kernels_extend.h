@@ -70,8 +70,12 @@ __global__ __launch_bounds__(kExtendBlock, 5) void k_extend(DScene sc, const f4 
     KdNode nd = {0u, kLeafTag};      // the 8 bytes of `node`
     f3 o = mk3(0.f, 0.f, 0.f), d = mk3(0.f, 0.f, 1.f);
     SlabBox cur;
+    PlaneValid val;  // which planes of `cur` carry a valid Box::intersect candidate (fast path only)
 #pragma unroll
-    for (int k = 0; k < 3; k++) cur.lo[k] = cur.hi[k] = cur.tlo[k] = cur.thi[k] = 0.f;
+    for (int k = 0; k < 3; k++) {
+        cur.lo[k] = cur.hi[k] = cur.tlo[k] = cur.thi[k] = 0.f;
+        val.lo[k] = val.hi[k] = false;
+    }
 
     // what follows a leaf visit: bt > 0 = accepted hit at triangle bi (mesh.cuh:300 ends this mesh; kernel.cu:149
     // keeps the earlier mesh on ties), else continue with the stacked far child, else the mesh is exhausted
@@ -153,10 +157,18 @@ __global__ __launch_bounds__(kExtendBlock, 5) void k_extend(DScene sc, const f4 
             node = sc.meshes[m].root;
             nd = sc.nodes[node];
             load_slab(sc, node, o, d, cur);
-            if (slab_hit(cur, o, d) > 0.0f) {
+            bool enter;
+            if (COUNT) {
+                enter = slab_hit(cur, o, d) > 0.0f;
+            } else {  // a mesh whose root cull box the ray misses cannot be hit: same outcome as walking it in vain
+                full_valid(cur, o, d, val);
+                enter = (valid_min(cur.tlo, cur.thi, val.lo, val.hi) > 0.0f) && !leaf_culled(sc, node, o, d);
+            }
+            if (enter) {
                 sp = 0;
                 start_mesh = false;
                 if (COUNT) { tc.pops++; tc.nodes++; }
+                else if ((nd.b >> 30) == 3u) pending = true;  // single-leaf mesh
             } else {
                 m++;  // the ray misses this mesh's root box
             }
@@ -178,43 +190,45 @@ __global__ __launch_bounds__(kExtendBlock, 5) void k_extend(DScene sc, const f4 
             }
         }
         // ---- continue with the far child that was stacked (mesh.cuh:263): its box is re-read --------------------
-        // A stacked subtree whose cull box (union of its leaves' cull boxes) the ray misses cannot produce a hit: it
-        // is dropped without being walked -- the continuation is the same as after walking it in vain.  (The
-        // counting variant walks everything so that its counters stay those of the reference traversal.)
-        while (need_pop) {
+        if (COUNT) {
+            if (need_pop) {
+                sp--;
+                node = stk.pop(sp);
+                nd = sc.nodes[node];
+                load_slab(sc, node, o, d, cur);
+                need_pop = false;
+                tc.pops++;
+                tc.nodes++;
+            }
+        } else if (need_pop) {  // only subtrees that passed their cull test were stacked (descend_fast)
             PSTAT(ps, 7);
             sp--;
             node = stk.pop(sp);
-            if (!COUNT && leaf_culled(sc, node, o, d)) {
-                if (sp == 0) {  // nothing left in this mesh
-                    need_pop = false;
-                    m++;
-                    start_mesh = true;
-                }
-                continue;
-            }
             nd = sc.nodes[node];
             load_slab(sc, node, o, d, cur);
+            full_valid(cur, o, d, val);
             need_pop = false;
-            if (COUNT) { tc.pops++; tc.nodes++; }
+            if ((nd.b >> 30) == 3u) pending = true;
         }
         if (!has_ray || pending || start_mesh) continue;
 
         // ---- walk down (at most step_cap steps per round), then the leaf visit ---------------------------------
         PSTAT(ps, 8);
-        const bool sub_culled = descend_to_leaf<LdsStack, COUNT, !COUNT>(sc, o, d, cur, node, nd, sp, stk, tc, tune.step_cap PSTAT_PASS);
-        if (sub_culled) {  // the subtree just entered cannot contain a hit: same continuation as a fruitless visit
-            after_leaf(-1.0f, -1);
-            continue;
-        }
-        if ((nd.b >> 30) != 3u) continue;  // out of steps for this round: keep walking next round
-        if (COUNT) { tc.refs += nd.b & kIdxMask; tc.tris += nd.b & kIdxMask; }
-        PSTAT(ps, 10);
-        if (!leaf_culled(sc, node, o, d)) {
-            pending = true;  // scanned later, together with other lanes' leaves
+        if (COUNT) {  // the reference's walk, node for node (its counters are the unit of SURVEY 8d)
+            descend_to_leaf<LdsStack, true>(sc, o, d, cur, node, nd, sp, stk, tc, tune.step_cap PSTAT_PASS);
+            if ((nd.b >> 30) != 3u) continue;  // out of steps for this round: keep walking next round
+            tc.refs += nd.b & kIdxMask;
+            tc.tris += nd.b & kIdxMask;
+            if (!leaf_culled(sc, node, o, d)) {
+                pending = true;  // scanned later, together with other lanes' leaves
+            } else {
+                tc.culled += nd.b & kIdxMask;
+                after_leaf(-1.0f, -1);
+            }
         } else {
-            if (COUNT) tc.culled += nd.b & kIdxMask;
-            after_leaf(-1.0f, -1);
+            const bool dead_end = descend_fast<LdsStack>(sc, o, d, cur, val, node, nd, sp, stk, tune.step_cap PSTAT_PASS);
+            if (dead_end) after_leaf(-1.0f, -1);                 // same continuation as a fruitless leaf visit
+            else if ((nd.b >> 30) == 3u) pending = true;        // a leaf that passed its cull test: scanned in a batch
         }
     }
     if (COUNT) flush_counters(tc, hit_tris, ctr);

@@ -28,7 +28,11 @@ constexpr int kStackDepth = 18;        // >= 16 interior levels + root (referenc
 constexpr int kMaxPathDepth = 16;      // accepted cam_depth / light_depth
 
 constexpr uint32_t kLeafTag = 3u << 30;
-constexpr uint32_t kIdxMask = (1u << 30) - 1;
+constexpr uint32_t kIdxMask = (1u << 29) - 1;
+// Interior nodes only (set by the packer): the split plane lies outside [lo, hi] of the node on its axis (possible
+// by one rounding of Box::half's lo + width*pct), so a child is not a subset of its parent and the incremental
+// plane-validity update of descend_fast() must be replaced by a full re-evaluation for the children.
+constexpr uint32_t kRecheckBit = 1u << 29;
 
 struct KdNode {
     uint32_t a, b;

@@ -125,6 +125,7 @@ PT_HD bool inside_triangle(f4 pl, f3 a, f3 b, f3 c, f3 o, f3 d, float t) {
 }
 
 PT_HD bool leaf_culled(const DScene &sc, int node, f3 o, f3 d);
+PT_HD bool box_culled(f4 b0, f4 b1, f3 o, f3 d);
 
 // Inner loop of Mesh::intersect (mesh.cuh:265-288): walk from `node` (whose 8 bytes are in `nd`) down towards a
 // leaf, pushing the far child when both children are hit (Q7).  `cur` (bounds + plane parameters of `node`)
@@ -178,6 +179,135 @@ PT_HD bool descend_to_leaf(const DScene &sc, f3 o, f3 d, SlabBox &cur, int &node
     return false;
 }
 
+// ---- the same walk, incrementally (the kernel's fast path; results identical to descend_to_leaf) ----------------
+//
+// Box::intersect is "smallest t > 0 among the six plane points that pass isVertexInBox".  Call plane j of a box
+// VALID when t_j > 0 and its point o + d t_j passes the six bound tests.  A child box is its parent with ONE bound
+// replaced by the split plane, so for the five planes it inherits (same t_j, same point):
+//       valid_child(j) = valid_parent(j)  AND  (the point passes the new bound),
+// because the replaced parent bound is implied by the tighter child bound (fp add is monotonic; the packer flags the
+// rare node whose split lies outside [lo, hi] with kRecheckBit and the children of such a node are re-evaluated in
+// full).  The new bound only involves the point's coordinate ALONG THE SPLIT AXIS: one mul + add per plane instead of
+// the whole point, one or two compares instead of six.  Only the split plane's own point is evaluated in full.
+// The six flags travel with the slab state; after the root / a stack pop they come from full_valid().
+struct PlaneValid {
+    bool lo[3], hi[3];
+};
+
+PT_HD void full_valid(const SlabBox &b, f3 o, f3 d, PlaneValid &v) {
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const float t0 = b.tlo[k], t1 = b.thi[k];
+        const f3 p0 = o + d * t0, p1 = o + d * t1;
+        v.lo[k] = (t0 > 0.0f) & point_in_box(p0, b.lo[0], b.hi[0], b.lo[1], b.hi[1], b.lo[2], b.hi[2]);
+        v.hi[k] = (t1 > 0.0f) & point_in_box(p1, b.lo[0], b.hi[0], b.lo[1], b.hi[1], b.lo[2], b.hi[2]);
+    }
+}
+// Box::intersect from the flags (== slab_hit of the same box)
+PT_HD float valid_min(const float tlo[3], const float thi[3], const bool vlo[3], const bool vhi[3]) {
+    const float inf = __builtin_inff();
+    float best = inf;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        best = fminf(best, vlo[k] ? tlo[k] : inf);  // the t's are never NaN where a flag is set
+        best = fminf(best, vhi[k] ? thi[k] : inf);
+    }
+    return (best < inf) ? best : -1.0f;
+}
+
+// Walks down from `node` for at most max_steps steps.  Every node this function stands on has passed its cull
+// test (see box_culled), and so has every node it pushes: a subtree the ray cannot hit anything in is neither
+// entered nor stacked -- visiting it is a no-op in the reference, whatever the order (Q7).  Returns true when
+// nothing below `node` is left to visit (dead end: the caller continues with the stack), false when it stopped on
+// `node` (a leaf, or an interior node if the steps ran out).
+template <class Stack>
+PT_HD bool descend_fast(const DScene &sc, f3 o, f3 d, SlabBox &cur, PlaneValid &val, int &node, KdNode &nd, int &sp, Stack &stk,
+                        int max_steps PSTAT_ARG) {
+    for (int step = 0; (nd.b >> 30) != 3u && step < max_steps; step++) {
+        PSTAT(ps, 9);
+        const uint32_t ax = nd.b >> 30;
+        const bool recheck = (nd.b & kRecheckBit) != 0u;
+        const int left = (int)(nd.b & kIdxMask), right = left + 1;
+        const KdNodePair pair = *reinterpret_cast<const KdNodePair *>(sc.nodes + left);
+        const f4 *tb = sc.tight + 2 * (size_t)left;  // the siblings' cull boxes are adjacent: 64 bytes
+        const f4 tl0 = tb[0], tl1 = tb[1], tr0 = tb[2], tr1 = tb[3];
+        const bool cull_l = box_culled(tl0, tl1, o, d), cull_r = box_culled(tr0, tr1, o, d);
+        if (cull_l & cull_r) return true;
+
+        const float s = as_f32(nd.a);
+        const float oa = ax == 0 ? o.x : (ax == 1 ? o.y : o.z);
+        const float da = ax == 0 ? d.x : (ax == 1 ? d.y : d.z);
+        const float ts = (s - oa) / da;
+        const float s_eps = s + kEps;
+        const float e_ax = ax == 0 ? 0.0f : kEps;  // Q5: min-X has no slack
+        // inherited planes: the new bound on the point's split-axis coordinate
+        bool vl_lo[3], vl_hi[3], vr_lo[3], vr_hi[3];
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            const float p0 = oa + da * cur.tlo[k], p1 = oa + da * cur.thi[k];
+            vl_lo[k] = val.lo[k] & (p0 <= s_eps);
+            vl_hi[k] = val.hi[k] & (p1 <= s_eps);
+            vr_lo[k] = val.lo[k] & (s <= p0 + e_ax);
+            vr_hi[k] = val.hi[k] & (s <= p1 + e_ax);
+        }
+        // the split plane's own point against the parent's bounds, then the one bound each child replaces
+        const f3 P = o + d * ts;
+        const float Pc[3] = {P.x, P.y, P.z};
+        bool in_lo[3], in_hi[3];
+        in_lo[0] = cur.lo[0] <= Pc[0];
+        in_lo[1] = cur.lo[1] <= Pc[1] + kEps;
+        in_lo[2] = cur.lo[2] <= Pc[2] + kEps;
+#pragma unroll
+        for (int k = 0; k < 3; k++) in_hi[k] = Pc[k] <= cur.hi[k] + kEps;
+        const float Pa = ax == 0 ? Pc[0] : (ax == 1 ? Pc[1] : Pc[2]);
+        bool split_l = (ts > 0.0f) & (Pa <= s_eps), split_r = (ts > 0.0f) & (s <= Pa + e_ax);
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            const bool on = ax == (uint32_t)k;
+            split_l &= in_lo[k] & (in_hi[k] | on);  // left box: hi[ax] is the split plane
+            split_r &= in_hi[k] & (in_lo[k] | on);  // right box: lo[ax] is the split plane
+        }
+        float tl_hi[3], tr_lo[3];
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            const bool on = ax == (uint32_t)k;
+            vl_hi[k] = on ? split_l : vl_hi[k];
+            vr_lo[k] = on ? split_r : vr_lo[k];
+            tl_hi[k] = on ? ts : cur.thi[k];
+            tr_lo[k] = on ? ts : cur.tlo[k];
+        }
+        const float lt = valid_min(cur.tlo, tl_hi, vl_lo, vl_hi);  // mesh.cuh:266-269
+        const float rt = valid_min(tr_lo, cur.thi, vr_lo, vr_hi);
+        const bool rf = rt < lt;              // Q7: a miss (-1) sorts first
+        const float small_t = rf ? rt : lt, big_t = rf ? lt : rt;
+        bool go_right = (small_t > 0.0f) ? rf : !rf;                 // mesh.cuh:281
+        const bool both = (small_t > 0.0f) & (big_t > 0.0f);         // mesh.cuh:285: the other child is stacked
+        const bool first_dead = go_right ? cull_r : cull_l, other_dead = go_right ? cull_l : cull_r;
+        if (first_dead) {
+            if (!both | other_dead) return true;  // nothing to find in the child the reference enters, nothing stacked
+            go_right = !go_right;                 // the fruitless visit is skipped: continue with the stacked child
+        } else if (both & !other_dead) {
+            if (sp < kStackDepth) stk.push(sp, go_right ? left : right);
+            sp++;
+        }
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            const bool on = ax == (uint32_t)k;
+            cur.lo[k] = (go_right & on) ? s : cur.lo[k];
+            cur.tlo[k] = go_right ? tr_lo[k] : cur.tlo[k];
+            cur.hi[k] = (!go_right & on) ? s : cur.hi[k];
+            cur.thi[k] = go_right ? cur.thi[k] : tl_hi[k];
+            val.lo[k] = go_right ? vr_lo[k] : vl_lo[k];
+            val.hi[k] = go_right ? vr_hi[k] : vl_hi[k];
+        }
+        node = go_right ? right : left;
+        nd.a = go_right ? pair.r.a : pair.l.a;
+        nd.b = go_right ? pair.r.b : pair.l.b;
+        if (recheck) full_valid(cur, o, d, val);
+    }
+    return false;
+}
+
 // Leaf loop of Mesh::intersect (mesh.cuh:290-299): leaf_culled() first, then leaf_scan().
 //
 // Leaf cull (no counterpart in the reference; it changes no result): an accepted hit point lies on a triangle of
@@ -185,8 +315,7 @@ PT_HD bool descend_to_leaf(const DScene &sc, f3 o, f3 d, SlabBox &cur, int &node
 // tested against that box grown by a margin of 2^-12 x (largest coordinate magnitude in play) -- thousands of ulps,
 // far beyond the rounding of P = o + d*t, of the fp32 edge tests and of the 1e-5 box slack -- with the standard
 // interval test.  A ray that misses the grown box cannot produce an accepted candidate, so the loop is skipped.
-PT_HD bool leaf_culled(const DScene &sc, int node, f3 o, f3 d) {
-    const f4 b0 = sc.tight[2 * (size_t)node], b1 = sc.tight[2 * (size_t)node + 1];
+PT_HD bool box_culled(f4 b0, f4 b1, f3 o, f3 d) {
     const float lo[3] = {b0.x, b0.z, b1.x}, hi[3] = {b0.y, b0.w, b1.y};
     const float oo[3] = {o.x, o.y, o.z}, dd[3] = {d.x, d.y, d.z};
     float tn = 0.0f, tf = __builtin_inff();
@@ -206,6 +335,9 @@ PT_HD bool leaf_culled(const DScene &sc, int node, f3 o, f3 d) {
     }
     // widen the interval itself by a relative margin as well (rounding of the divisions)
     return out | (tn > tf + 2.44140625e-4f * (fabsf(tf) + 1.0f)) | !(lo[0] <= hi[0]);
+}
+PT_HD bool leaf_culled(const DScene &sc, int node, f3 o, f3 d) {
+    return box_culled(sc.tight[2 * (size_t)node], sc.tight[2 * (size_t)node + 1], o, d);
 }
 
 PT_HD void leaf_scan(const DScene &sc, int first, int count, f3 o, f3 d, const SlabBox &cur, float &bt, int &bi PSTAT_ARG);
