@@ -69,13 +69,9 @@ __global__ __launch_bounds__(kExtendBlock, 5) void k_extend(DScene sc, const f4 
     float best = -1.0f, q_t = -1.0f;
     KdNode nd = {0u, kLeafTag};      // the 8 bytes of `node`
     f3 o = mk3(0.f, 0.f, 0.f), d = mk3(0.f, 0.f, 1.f);
-    SlabBox cur;
-    PlaneValid val;  // which planes of `cur` carry a valid Box::intersect candidate (fast path only)
+    SlabBox cur;  // fast path: a masked slab (see descend_fast)
 #pragma unroll
-    for (int k = 0; k < 3; k++) {
-        cur.lo[k] = cur.hi[k] = cur.tlo[k] = cur.thi[k] = 0.f;
-        val.lo[k] = val.hi[k] = false;
-    }
+    for (int k = 0; k < 3; k++) cur.lo[k] = cur.hi[k] = cur.tlo[k] = cur.thi[k] = 0.f;
 
     // what follows a leaf visit: bt > 0 = accepted hit at triangle bi (mesh.cuh:300 ends this mesh; kernel.cu:149
     // keeps the earlier mesh on ties), else continue with the stacked far child, else the mesh is exhausted
@@ -161,8 +157,8 @@ __global__ __launch_bounds__(kExtendBlock, 5) void k_extend(DScene sc, const f4 
             if (COUNT) {
                 enter = slab_hit(cur, o, d) > 0.0f;
             } else {  // a mesh whose root cull box the ray misses cannot be hit: same outcome as walking it in vain
-                full_valid(cur, o, d, val);
-                enter = (valid_min(cur.tlo, cur.thi, val.lo, val.hi) > 0.0f) && !leaf_culled(sc, node, o, d);
+                mask_slab(cur, o, d);
+                enter = (masked_min(cur.tlo, cur.thi) > 0.0f) && !leaf_culled(sc, node, o, d);
             }
             if (enter) {
                 sp = 0;
@@ -206,7 +202,7 @@ __global__ __launch_bounds__(kExtendBlock, 5) void k_extend(DScene sc, const f4 
             node = stk.pop(sp);
             nd = sc.nodes[node];
             load_slab(sc, node, o, d, cur);
-            full_valid(cur, o, d, val);
+            mask_slab(cur, o, d);
             need_pop = false;
             if ((nd.b >> 30) == 3u) pending = true;
         }
@@ -226,7 +222,7 @@ __global__ __launch_bounds__(kExtendBlock, 5) void k_extend(DScene sc, const f4 
                 after_leaf(-1.0f, -1);
             }
         } else {
-            const bool dead_end = descend_fast<LdsStack>(sc, o, d, cur, val, node, nd, sp, stk, tune.step_cap PSTAT_PASS);
+            const bool dead_end = descend_fast<LdsStack>(sc, o, d, cur, node, nd, sp, stk, tune.step_cap PSTAT_PASS);
             if (dead_end) after_leaf(-1.0f, -1);                 // same continuation as a fruitless leaf visit
             else if ((nd.b >> 30) == 3u) pending = true;        // a leaf that passed its cull test: scanned in a batch
         }

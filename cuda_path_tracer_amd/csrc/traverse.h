@@ -188,41 +188,37 @@ PT_HD bool descend_to_leaf(const DScene &sc, f3 o, f3 d, SlabBox &cur, int &node
 // because the replaced parent bound is implied by the tighter child bound (fp add is monotonic; the packer flags the
 // rare node whose split lies outside [lo, hi] with kRecheckBit and the children of such a node are re-evaluated in
 // full).  The new bound only involves the point's coordinate ALONG THE SPLIT AXIS: one mul + add per plane instead of
-// the whole point, one or two compares instead of six.  Only the split plane's own point is evaluated in full.
-// The six flags travel with the slab state; after the root / a stack pop they come from full_valid().
-struct PlaneValid {
-    bool lo[3], hi[3];
-};
-
-PT_HD void full_valid(const SlabBox &b, f3 o, f3 d, PlaneValid &v) {
+// the whole point, one compare instead of six.  Only the split plane's own point is evaluated in full.
+// A plane that is not valid never becomes valid further down, so its t is never needed again: the slab state of the
+// fast path stores +inf in its place ("masked" t), and Box::intersect is a plain minimum.  (For a masked entry the
+// coordinate below is +-inf or NaN; whatever the compare says, the entry stays +inf.)
+PT_HD void mask_slab(SlabBox &b, f3 o, f3 d) {
+    const float inf = __builtin_inff();
 #pragma unroll
     for (int k = 0; k < 3; k++) {
         const float t0 = b.tlo[k], t1 = b.thi[k];
         const f3 p0 = o + d * t0, p1 = o + d * t1;
-        v.lo[k] = (t0 > 0.0f) & point_in_box(p0, b.lo[0], b.hi[0], b.lo[1], b.hi[1], b.lo[2], b.hi[2]);
-        v.hi[k] = (t1 > 0.0f) & point_in_box(p1, b.lo[0], b.hi[0], b.lo[1], b.hi[1], b.lo[2], b.hi[2]);
+        const bool ok0 = (t0 > 0.0f) & point_in_box(p0, b.lo[0], b.hi[0], b.lo[1], b.hi[1], b.lo[2], b.hi[2]);
+        const bool ok1 = (t1 > 0.0f) & point_in_box(p1, b.lo[0], b.hi[0], b.lo[1], b.hi[1], b.lo[2], b.hi[2]);
+        b.tlo[k] = ok0 ? t0 : inf;
+        b.thi[k] = ok1 ? t1 : inf;
     }
 }
-// Box::intersect from the flags (== slab_hit of the same box)
-PT_HD float valid_min(const float tlo[3], const float thi[3], const bool vlo[3], const bool vhi[3]) {
-    const float inf = __builtin_inff();
-    float best = inf;
-#pragma unroll
-    for (int k = 0; k < 3; k++) {
-        best = fminf(best, vlo[k] ? tlo[k] : inf);  // the t's are never NaN where a flag is set
-        best = fminf(best, vhi[k] ? thi[k] : inf);
-    }
-    return (best < inf) ? best : -1.0f;
+// Box::intersect of a masked slab (== slab_hit of the same box)
+PT_HD float masked_min(const float tlo[3], const float thi[3]) {
+    const float best = fminf(fminf(fminf(tlo[0], thi[0]), fminf(tlo[1], thi[1])), fminf(tlo[2], thi[2]));
+    return (best < __builtin_inff()) ? best : -1.0f;
 }
 
-// Walks down from `node` for at most max_steps steps.  Every node this function stands on has passed its cull
-// test (see box_culled), and so has every node it pushes: a subtree the ray cannot hit anything in is neither
-// entered nor stacked -- visiting it is a no-op in the reference, whatever the order (Q7).  Returns true when
-// nothing below `node` is left to visit (dead end: the caller continues with the stack), false when it stopped on
-// `node` (a leaf, or an interior node if the steps ran out).
+// Walks down from `node` for at most max_steps steps; `cur` is a MASKED slab.  Every node this function stands on
+// has passed its cull test (see box_culled), and so has every node it pushes: a subtree the ray cannot hit anything
+// in is neither entered nor stacked -- visiting it is a no-op in the reference, whatever the order (Q7).  Returns
+// true when nothing below `node` is left to visit (dead end: the caller continues with the stack), false when it
+// stopped on `node` (a leaf, or an interior node if the steps ran out).
 template <class Stack>
-PT_HD bool descend_fast(const DScene &sc, f3 o, f3 d, SlabBox &cur, PlaneValid &val, int &node, KdNode &nd, int &sp, Stack &stk,
+PT_HD bool descend_fast(const DScene &sc, f3 o, f3 d, SlabBox &cur, int &node, KdNode &nd, int &sp, Stack &stk,
                         int max_steps PSTAT_ARG) {
+    const float inf = __builtin_inff();
     for (int step = 0; (nd.b >> 30) != 3u && step < max_steps; step++) {
         PSTAT(ps, 9);
         const uint32_t ax = nd.b >> 30;
@@ -241,14 +237,14 @@ PT_HD bool descend_fast(const DScene &sc, f3 o, f3 d, SlabBox &cur, PlaneValid &
         const float s_eps = s + kEps;
         const float e_ax = ax == 0 ? 0.0f : kEps;  // Q5: min-X has no slack
         // inherited planes: the new bound on the point's split-axis coordinate
-        bool vl_lo[3], vl_hi[3], vr_lo[3], vr_hi[3];
+        float l_lo[3], l_hi[3], r_lo[3], r_hi[3];
 #pragma unroll
         for (int k = 0; k < 3; k++) {
             const float p0 = oa + da * cur.tlo[k], p1 = oa + da * cur.thi[k];
-            vl_lo[k] = val.lo[k] & (p0 <= s_eps);
-            vl_hi[k] = val.hi[k] & (p1 <= s_eps);
-            vr_lo[k] = val.lo[k] & (s <= p0 + e_ax);
-            vr_hi[k] = val.hi[k] & (s <= p1 + e_ax);
+            l_lo[k] = (p0 <= s_eps) ? cur.tlo[k] : inf;
+            l_hi[k] = (p1 <= s_eps) ? cur.thi[k] : inf;
+            r_lo[k] = (s <= p0 + e_ax) ? cur.tlo[k] : inf;
+            r_hi[k] = (s <= p1 + e_ax) ? cur.thi[k] : inf;
         }
         // the split plane's own point against the parent's bounds, then the one bound each child replaces
         const f3 P = o + d * ts;
@@ -267,17 +263,15 @@ PT_HD bool descend_fast(const DScene &sc, f3 o, f3 d, SlabBox &cur, PlaneValid &
             split_l &= in_lo[k] & (in_hi[k] | on);  // left box: hi[ax] is the split plane
             split_r &= in_hi[k] & (in_lo[k] | on);  // right box: lo[ax] is the split plane
         }
-        float tl_hi[3], tr_lo[3];
+        const float ts_l = split_l ? ts : inf, ts_r = split_r ? ts : inf;
 #pragma unroll
         for (int k = 0; k < 3; k++) {
             const bool on = ax == (uint32_t)k;
-            vl_hi[k] = on ? split_l : vl_hi[k];
-            vr_lo[k] = on ? split_r : vr_lo[k];
-            tl_hi[k] = on ? ts : cur.thi[k];
-            tr_lo[k] = on ? ts : cur.tlo[k];
+            l_hi[k] = on ? ts_l : l_hi[k];
+            r_lo[k] = on ? ts_r : r_lo[k];
         }
-        const float lt = valid_min(cur.tlo, tl_hi, vl_lo, vl_hi);  // mesh.cuh:266-269
-        const float rt = valid_min(tr_lo, cur.thi, vr_lo, vr_hi);
+        const float lt = masked_min(l_lo, l_hi);  // mesh.cuh:266-269
+        const float rt = masked_min(r_lo, r_hi);
         const bool rf = rt < lt;              // Q7: a miss (-1) sorts first
         const float small_t = rf ? rt : lt, big_t = rf ? lt : rt;
         bool go_right = (small_t > 0.0f) ? rf : !rf;                 // mesh.cuh:281
@@ -294,16 +288,17 @@ PT_HD bool descend_fast(const DScene &sc, f3 o, f3 d, SlabBox &cur, PlaneValid &
         for (int k = 0; k < 3; k++) {
             const bool on = ax == (uint32_t)k;
             cur.lo[k] = (go_right & on) ? s : cur.lo[k];
-            cur.tlo[k] = go_right ? tr_lo[k] : cur.tlo[k];
             cur.hi[k] = (!go_right & on) ? s : cur.hi[k];
-            cur.thi[k] = go_right ? cur.thi[k] : tl_hi[k];
-            val.lo[k] = go_right ? vr_lo[k] : vl_lo[k];
-            val.hi[k] = go_right ? vr_hi[k] : vl_hi[k];
+            cur.tlo[k] = go_right ? r_lo[k] : l_lo[k];
+            cur.thi[k] = go_right ? r_hi[k] : l_hi[k];
         }
         node = go_right ? right : left;
         nd.a = go_right ? pair.r.a : pair.l.a;
         nd.b = go_right ? pair.r.b : pair.l.b;
-        if (recheck) full_valid(cur, o, d, val);
+        if (recheck) {  // rare: rebuild the child's slab from its stored box
+            load_slab(sc, node, o, d, cur);
+            mask_slab(cur, o, d);
+        }
     }
     return false;
 }
