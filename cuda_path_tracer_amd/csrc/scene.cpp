@@ -320,6 +320,7 @@ bool HostScene::pack(int n_threads, std::string &err) {
     L.nodes = section((size_t)total_nodes * sizeof(KdNode));
     L.boxes = section((size_t)total_nodes * 32);
     L.tight = section((size_t)total_nodes * 32);
+    L.tight_pairs = section((size_t)(total_nodes / 2 + 1) * 64);
     L.refs = section((size_t)total_refs * 4);
     L.leaf_planes = section((size_t)total_refs * 16);
     L.leaf_spheres = section(((size_t)total_refs / 2 + 4) * sizeof(SpherePair));  // + padding the scan may over-read
@@ -394,6 +395,22 @@ bool HostScene::pack(int n_threads, std::string &err) {
             for (int a = 0; a < 3; a++) {
                 tb[2 * a] = std::min(l[2 * a], r[2 * a]);
                 tb[2 * a + 1] = std::max(l[2 * a + 1], r[2 * a + 1]);
+            }
+        }
+        // the same boxes once more, interleaved per sibling pair for the packed cull test of descend_fast()
+        if ((hm.node_base & 1) != 0) { err = "internal: odd node base"; return false; }
+        float *tpair = reinterpret_cast<float *>(A + L.tight_pairs);
+        for (int64_t i = 0; i < hm.n_nodes; i++) {
+            const KdNode k = t.nodes[(size_t)i];
+            if ((k.b >> 30) == 3u) continue;
+            const size_t lc = (size_t)(k.b & kIdxMask);
+            const float *l = tight + 8 * lc, *r = l + 8;
+            float *rec = tpair + 16 * (((size_t)hm.node_base + lc) >> 1);
+            for (int a = 0; a < 3; a++) {
+                rec[4 * a + 0] = l[2 * a];
+                rec[4 * a + 1] = r[2 * a];
+                rec[4 * a + 2] = l[2 * a + 1];
+                rec[4 * a + 3] = r[2 * a + 1];
             }
         }
         int32_t *refs = reinterpret_cast<int32_t *>(A + L.refs) + hm.ref_base;
@@ -548,6 +565,7 @@ DScene HostScene::view(const void *base_v) const {
     d.nodes = reinterpret_cast<const KdNode *>(base + layout.nodes);
     d.boxes = reinterpret_cast<const f4 *>(base + layout.boxes);
     d.tight = reinterpret_cast<const f4 *>(base + layout.tight);
+    d.tight_pairs = reinterpret_cast<const f4 *>(base + layout.tight_pairs);
     d.refs = reinterpret_cast<const int32_t *>(base + layout.refs);
     d.leaf_planes = reinterpret_cast<const f4 *>(base + layout.leaf_planes);
     d.leaf_spheres = reinterpret_cast<const SpherePair *>(base + layout.leaf_spheres);

@@ -57,6 +57,18 @@ PT_HD uint32_t as_u32(float f) {
     return c.u;
 }
 
+// One-instruction min / max for operands that are never NaN (fminf/fmaxf add a canonicalising v_max x,x per operand
+// the compiler cannot prove quiet; a compare + select is two instructions).
+#if defined(__HIP_DEVICE_COMPILE__)
+PT_HD float fmin_raw(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+PT_HD float fmax_raw(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+PT_HD float fmin3_raw(float a, float b, float c) { float r; asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+#else
+PT_HD float fmin_raw(float a, float b) { return a < b ? a : b; }
+PT_HD float fmax_raw(float a, float b) { return a > b ? a : b; }
+PT_HD float fmin3_raw(float a, float b, float c) { return fmin_raw(fmin_raw(a, b), c); }
+#endif
+
 // Box::isVertexInBox (mesh.cuh:131-139): min-X has no epsilon, every other bound has +eps slack (Q5)
 PT_HD bool point_in_box(f3 p, float lox, float hix, float loy, float hiy, float loz, float hiz) {
     return (lox <= p.x) & (p.x <= hix + kEps) & (loy <= p.y + kEps) & (p.y <= hiy + kEps) & (loz <= p.z + kEps) &
@@ -206,8 +218,38 @@ PT_HD void mask_slab(SlabBox &b, f3 o, f3 d) {
 }
 // Box::intersect of a masked slab (== slab_hit of the same box)
 PT_HD float masked_min(const float tlo[3], const float thi[3]) {
-    const float best = fminf(fminf(fminf(tlo[0], thi[0]), fminf(tlo[1], thi[1])), fminf(tlo[2], thi[2]));
+    const float best = fmin_raw(fmin3_raw(tlo[0], thi[0], tlo[1]), fmin3_raw(thi[1], tlo[2], thi[2]));
     return (best < __builtin_inff()) ? best : -1.0f;
+}
+
+// box_culled() for the two children of a node at once: their cull boxes come component-interleaved (scene_types.h),
+// so growing them and turning them into ray parameters is packed fp32 work on (left, right) pairs.
+PT_HD void pair_culled(f4 bx, f4 by, f4 bz, f3 o, f3 d, bool &cull_l, bool &cull_r) {
+    const f4 bb[3] = {bx, by, bz};
+    const float oo[3] = {o.x, o.y, o.z}, dd[3] = {d.x, d.y, d.z};
+    float tn_l = 0.0f, tf_l = __builtin_inff(), tn_r = 0.0f, tf_r = __builtin_inff();
+    bool out_l = false, out_r = false;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const v2f lo = {bb[k].x, bb[k].y}, hi = {bb[k].z, bb[k].w};
+        const float ob = fmaxf(fabsf(oo[k]), 1.0f);
+        const v2f m = {fmaxf(fmaxf(fabsf(lo.x), fabsf(hi.x)), ob), fmaxf(fmaxf(fabsf(lo.y), fabsf(hi.y)), ob)};
+        const v2f mg = m * 2.44140625e-4f;  // (an empty box, lo = +inf > hi, only spoils its own half: see the last lines)
+        const v2f l = lo - mg, h = hi + mg;
+        if (fabsf(dd[k]) < 1e-30f) {
+            out_l |= (oo[k] < l.x) | (oo[k] > h.x);
+            out_r |= (oo[k] < l.y) | (oo[k] > h.y);
+        } else {
+            const float inv = __frcp_rn(dd[k]);
+            const v2f t0 = (l - oo[k]) * inv, t1 = (h - oo[k]) * inv;
+            tn_l = fmax_raw(tn_l, fmin_raw(t0.x, t1.x));
+            tf_l = fmin_raw(tf_l, fmax_raw(t0.x, t1.x));
+            tn_r = fmax_raw(tn_r, fmin_raw(t0.y, t1.y));
+            tf_r = fmin_raw(tf_r, fmax_raw(t0.y, t1.y));
+        }
+    }
+    cull_l = out_l | (tn_l > tf_l + 2.44140625e-4f * (fabsf(tf_l) + 1.0f)) | !(bx.x <= bx.z);
+    cull_r = out_r | (tn_r > tf_r + 2.44140625e-4f * (fabsf(tf_r) + 1.0f)) | !(bx.y <= bx.w);
 }
 
 // Walks down from `node` for at most max_steps steps; `cur` is a MASKED slab.  Every node this function stands on
@@ -225,9 +267,10 @@ PT_HD bool descend_fast(const DScene &sc, f3 o, f3 d, SlabBox &cur, int &node, K
         const bool recheck = (nd.b & kRecheckBit) != 0u;
         const int left = (int)(nd.b & kIdxMask), right = left + 1;
         const KdNodePair pair = *reinterpret_cast<const KdNodePair *>(sc.nodes + left);
-        const f4 *tb = sc.tight + 2 * (size_t)left;  // the siblings' cull boxes are adjacent: 64 bytes
-        const f4 tl0 = tb[0], tl1 = tb[1], tr0 = tb[2], tr1 = tb[3];
-        const bool cull_l = box_culled(tl0, tl1, o, d), cull_r = box_culled(tr0, tr1, o, d);
+        const f4 *tb = sc.tight_pairs + 2 * (size_t)left;  // 4 float4 per sibling pair, pair index = left / 2
+        const f4 tbx = tb[0], tby = tb[1], tbz = tb[2];
+        bool cull_l, cull_r;
+        pair_culled(tbx, tby, tbz, o, d, cull_l, cull_r);
         if (cull_l & cull_r) return true;
 
         const float s = as_f32(nd.a);
