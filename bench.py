@@ -206,6 +206,18 @@ def main():
                          "rays_per_launch": round(tot["rays_extended"] / max(1, tot["extend_launches"])),
                          "Mrays_per_s_in_kernel": round(tot["rays_extended"] / ext_s / 1e6, 1)},
         }
+        # HBM bytes per k_extend launch: PMC counters cannot be read inside this process, so the figure is taken from the
+        # committed summary of `scripts/pmc_bench.sh` (the same workload under separate rocprofv3 --pmc passes), if present
+        pmc_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r1_pmc_bench_c2.json")
+        if os.path.exists(pmc_path):
+            try:
+                tb = json.load(open(pmc_path))["traffic_bytes_per_launch"]
+                line["roofline"]["traffic"] = round(tb["read_raw"] + tb["write"])
+                line["roofline"]["traffic_unit"] = "bytes per launch (TCC FETCH_SIZE + WRITE_SIZE, raw)"
+                line["roofline"]["traffic_source"] = "profiles/r1_pmc_bench_c2.json"
+                line["roofline"]["algorithmic_bytes_per_launch"] = round(bpr * tot["rays_extended"] / max(1, tot["extend_launches"]))
+            except (KeyError, ValueError):
+                pass
         if not args.no_cpu_baseline and world == 1:
             from oracle.binding import OracleScene
             orc = desc.apply(OracleScene(threads=cpu_threads()))
