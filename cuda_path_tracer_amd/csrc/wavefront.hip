@@ -498,10 +498,11 @@ int wavefront_render(const HostScene &hs, DeviceCtx &dc, const mipt_render_confi
     WF_TRY(hipSetDevice(dc.device));
     if (n_samples == 0 || Dc == 0) return 0;
     int S = cfg.samples_per_pass;
-    // auto: ~16 M paths per pass.  The persistent extend kernel holds ~330 k rays at a time; queues much shorter than
-    // ~10x that spend most of their launch in ramp-up and tail (1080p: 1 sample/pass 122 -> 8 samples/pass 202 Msamples/s)
-    if (S <= 0) S = (int)std::max<int64_t>(1, ((int64_t)1 << 24) / npix);
-    S = (int)std::min<int64_t>(std::min<int64_t>(S, n_samples), std::max<int64_t>(1, ((int64_t)1 << 27) / ((int64_t)npix * K)));
+    // auto: ~64 M paths per pass (11 GB of path state for simple PT, 4 % of the HBM).  The persistent extend kernel holds
+    // ~330 k rays at a time and every launch pays a ramp-up and a tail in which its waves run dry one by one; at 1080p
+    // that costs 122 -> 285 -> 349 -> 384 -> 402 -> 412 Msamples/s for 1, 2, 4, 8, 16, 32 samples of every pixel per pass
+    if (S <= 0) S = (int)std::max<int64_t>(1, ((int64_t)1 << 26) / npix);
+    S = (int)std::min<int64_t>(std::min<int64_t>(S, n_samples), std::max<int64_t>(1, ((int64_t)1 << 28) / ((int64_t)npix * K)));
     const size_t P = (size_t)S * npix;
 
     size_t sizes[28] = {0};
