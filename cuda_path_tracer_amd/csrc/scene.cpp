@@ -352,6 +352,8 @@ bool HostScene::pack(int n_threads, std::string &err) {
             nodes[i] = k;
         }
         memcpy(A + L.boxes + (size_t)hm.node_base * 32, t.boxes.data(), (size_t)hm.n_nodes * 32);
+        // MIPT_FORCE_RECHECK=1 (tests): flag every interior node, so the full re-evaluation path is exercised everywhere
+        const bool force_recheck = getenv("MIPT_FORCE_RECHECK") && atoi(getenv("MIPT_FORCE_RECHECK")) != 0;
         for (int64_t i = 0; i < hm.n_nodes; i++) {  // kRecheckBit: split plane outside the node's own extent (see scene_types.h)
             const KdNode k = t.nodes[(size_t)i];
             const uint32_t ax = k.b >> 30;
@@ -359,7 +361,7 @@ bool HostScene::pack(int n_threads, std::string &err) {
             const float *nb = t.boxes.data() + 8 * (size_t)i;
             float sv;
             memcpy(&sv, &k.a, 4);
-            if (!(nb[2 * ax] <= sv && sv <= nb[2 * ax + 1])) nodes[i].b |= kRecheckBit;
+            if (force_recheck || !(nb[2 * ax] <= sv && sv <= nb[2 * ax + 1])) nodes[i].b |= kRecheckBit;
         }
         // per-leaf cull box: (AABB of the leaf's triangles) intersected with the leaf box.  An accepted hit point lies
         // on one of those triangles AND inside the leaf box (mesh.cuh:293-296), so a ray that misses this box -- tested

@@ -24,18 +24,46 @@ def _rays(desc, n):
     return np.concatenate([o1, o2]), np.concatenate([d1, d2])
 
 
-def _check(desc, n):
+def _same(gp, gt, op, ot, what):
+    mism = np.flatnonzero(gp != op)
+    assert mism.size == 0, f"{what}: {mism.size} prim mismatches, first {mism[:5]}: gpu {gp[mism[:5]]} oracle {op[mism[:5]]}"
+    assert np.array_equal(gt.view(np.uint32), ot.view(np.uint32)), f"{what}: t differs bitwise"
+
+
+def _check(desc, n, lattice=0):
+    """Both kernels against the oracle: the counting one (the reference's walk node for node, counters equal to the
+    oracle's) and the production one (incremental descent, cull boxes, candidate spheres)."""
     s, o = _pair(desc)
     ro, rd = _rays(desc, n)
-    gp, gt, st = s.trace_closest(ro, rd, counters=True)
+    if lattice:
+        lo_, ld_ = _grid_rays(s, lattice)
+        ro, rd = np.concatenate([ro, lo_]), np.concatenate([rd, ld_])
     op, ot, ctr = o.trace_closest(ro, rd)
-    mism = np.flatnonzero(gp != op)
-    assert mism.size == 0, f"{mism.size} prim mismatches, first {mism[:5]}: gpu {gp[mism[:5]]} oracle {op[mism[:5]]}"
-    assert np.array_equal(gt.view(np.uint32), ot.view(np.uint32)), "t differs bitwise"
+    gp, gt, st = s.trace_closest(ro, rd, counters=True)
+    _same(gp, gt, op, ot, "counting kernel")
     for k in ("nodes", "pops", "refs", "tris", "hits"):
         assert st["ctr_" + k] == ctr[k], (k, st["ctr_" + k], ctr[k])
-    assert (gp >= 0).mean() > 0.5
+    fp, ft, _ = s.trace_closest(ro, rd)
+    _same(fp, ft, op, ot, "production kernel")
+    assert (gp >= 0).mean() > 0.3
     return s, o
+
+
+def _grid_rays(scene, n_side=24):
+    """Axis-parallel and diagonal rays from a lattice that includes mesh vertex coordinates (origins ON split planes
+    and box faces, zero direction components: the +-inf / NaN corners of the slab arithmetic)."""
+    pos = np.concatenate([scene.mesh_triangles(m)[0].reshape(-1, 3) for m in range(scene.mesh_count())])
+    lo, hi = np.array([-3.0, -3.5, -4.5], np.float32), np.array([3.0, 1.5, 0.5], np.float32)
+    g = np.linspace(0.0, 1.0, n_side, dtype=np.float32)
+    pts = np.stack(np.meshgrid(g, g, g, indexing="ij"), -1).reshape(-1, 3) * (hi - lo) + lo
+    if len(pos):
+        rng = np.random.Generator(np.random.Philox(key=7))
+        pts = np.concatenate([pts, pos[rng.integers(0, len(pos), 4096)]]).astype(np.float32)
+    dirs = np.array([[1, 0, 0], [-1, 0, 0], [0, 1, 0], [0, -1, 0], [0, 0, 1], [0, 0, -1], [1, 1, 0], [0, -1, 1], [-1, 0, 1],
+                     [1, 1, 1], [-1, 1, -1]], np.float32)
+    ro = np.repeat(pts, len(dirs), axis=0)
+    rd = np.tile(dirs, (len(pts), 1))
+    return np.ascontiguousarray(ro), np.ascontiguousarray(rd)
 
 
 def test_default_scene(cube_obj):
@@ -44,6 +72,24 @@ def test_default_scene(cube_obj):
 
 def test_icosphere_l4():
     _check(G.scene_icosphere_room(4), 8192)
+
+
+def test_lattice_rays_default_scene(cube_obj):
+    desc = G.scene_default(cube_obj)
+    _check(desc, 1024, lattice=12)
+
+
+def test_lattice_rays_icosphere():
+    desc = G.scene_icosphere_room(5)
+    _check(desc, 1024, lattice=20)
+
+
+def test_forced_recheck_path(monkeypatch):
+    """Every interior node flagged kRecheckBit: the children's slabs are rebuilt from their stored boxes instead of
+    being derived incrementally; results must not change."""
+    monkeypatch.setenv("MIPT_FORCE_RECHECK", "1")
+    desc = G.scene_icosphere_room(5)
+    _check(desc, 32768, lattice=10)
 
 
 def test_icosphere_l6():
