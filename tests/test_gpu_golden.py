@@ -74,6 +74,8 @@ def test_reference_and_persistent_kernels_agree():
     for k in ("ctr_nodes", "ctr_pops", "ctr_refs", "ctr_tris", "ctr_hits", "ctr_culled"):
         assert a[2][k] == b[2][k], k
     assert b[2]["ctr_culled"] > 0
+    c = _gpu(desc).trace_closest(ro, rd)  # production kernel
+    assert np.array_equal(a[0], c[0]) and np.array_equal(a[1].view(np.uint32), c[1].view(np.uint32))
 
 
 def test_full_size_c2_frame_on_pixel_subset():
@@ -101,6 +103,9 @@ def test_full_size_1m_triangle_mesh_on_ray_subset():
     sel = np.arange(0, 1 << 20, 64)
     op, ot, _ = o.trace_closest(ro[sel], rd[sel])
     assert np.array_equal(prim[sel], op) and np.array_equal(t[sel].view(np.uint32), ot.view(np.uint32))
+    # the production kernel (incremental descent, cull boxes, candidate spheres) against the counting one, all 2^20 rays
+    fprim, ft, _ = s.trace_closest(ro, rd)
+    assert np.array_equal(fprim, prim) and np.array_equal(ft.view(np.uint32), t.view(np.uint32))
     hit = prim >= 0
     assert 0.8 < hit.mean() <= 1.0 and (t[hit] > 0).all() and (t[~hit] == -1).all()
     # property: a reported triangle hit really lies on the unit-direction ray at distance t from the sphere centre ~2.5
