@@ -323,6 +323,7 @@ bool HostScene::pack(int n_threads, std::string &err) {
     L.tight_pairs = section((size_t)(total_nodes / 2 + 1) * 64);
     L.refs = section((size_t)total_refs * 4);
     L.leaf_planes = section((size_t)total_refs * 16);
+    L.leaf_verts = section((size_t)total_refs * 48);
     L.leaf_spheres = section(((size_t)total_refs / 2 + 4) * sizeof(SpherePair));  // + padding the scan may over-read
     L.tri_pos = section((size_t)total_tris * 48);
     L.tri_nrm = section((size_t)total_tris * 48);
@@ -426,6 +427,12 @@ bool HostScene::pack(int n_threads, std::string &err) {
             const f3 N = cross3(b - a, c - a);
             lp[4 * i] = N.x; lp[4 * i + 1] = N.y; lp[4 * i + 2] = N.z;
             lp[4 * i + 3] = -dot3(N, a);
+        }
+        float *lv = reinterpret_cast<float *>(A + L.leaf_verts) + (size_t)hm.ref_base * 12;
+        for (int64_t i = 0; i < hm.n_refs; i++) {
+            const float *v = hm.pos.data() + (size_t)t.refs[(size_t)i] * 9;
+            for (int q = 0; q < 3; q++)
+                for (int c = 0; c < 3; c++) lv[12 * i + 4 * q + c] = v[3 * q + c];
         }
         // leaf-ordered candidate spheres (no counterpart in the reference; they change no result): a hit the leaf
         // loop accepts lies on the triangle (up to the rounding of the edge tests) and inside the leaf box (up to its
@@ -571,6 +578,7 @@ DScene HostScene::view(const void *base_v) const {
     d.refs = reinterpret_cast<const int32_t *>(base + layout.refs);
     d.leaf_planes = reinterpret_cast<const f4 *>(base + layout.leaf_planes);
     d.leaf_spheres = reinterpret_cast<const SpherePair *>(base + layout.leaf_spheres);
+    d.leaf_verts = reinterpret_cast<const f4 *>(base + layout.leaf_verts);
     d.tri_pos = reinterpret_cast<const f4 *>(base + layout.tri_pos);
     d.tri_nrm = reinterpret_cast<const f4 *>(base + layout.tri_nrm);
     d.meshes = reinterpret_cast<const DMesh *>(base + layout.meshes);

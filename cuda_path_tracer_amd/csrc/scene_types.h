@@ -71,6 +71,8 @@ struct DScene {
     const f4 *leaf_planes;  // per leaf reference: (N.xyz, -dot(N,a)) of that triangle, in leaf order
     const SpherePair *leaf_spheres;  // per PAIR of leaf references (global reference index >> 1): spheres that contain
                                      // every hit point the leaf loop could accept for that reference
+    const f4 *leaf_verts;   // per leaf reference: the triangle's vertex positions a,b,c again (3 float4), in leaf order, so the
+                            // exact test of a marked candidate issues all its loads at once (no reference -> triangle hop)
     const f4 *tri_pos;
     const f4 *tri_nrm;
     const DMesh *meshes;

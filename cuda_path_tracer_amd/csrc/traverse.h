@@ -442,15 +442,15 @@ PT_HD void leaf_scan(const DScene &sc, int first, int count, f3 o, f3 d, const S
             const f4 pl = sc.leaf_planes[r];
             const float t = plane_candidate(pl, o, d, cur, bt);
             if (t > 0.0f) {
-                const int tri = sc.refs[r];
-                const f4 pa = sc.tri_pos[3 * (size_t)tri], pb = sc.tri_pos[3 * (size_t)tri + 1], pc = sc.tri_pos[3 * (size_t)tri + 2];
+                const f4 pa = sc.leaf_verts[3 * (size_t)r], pb = sc.leaf_verts[3 * (size_t)r + 1], pc = sc.leaf_verts[3 * (size_t)r + 2];
                 if (inside_triangle(pl, mk3(pa.x, pa.y, pa.z), mk3(pb.x, pb.y, pb.z), mk3(pc.x, pc.y, pc.z), o, d, t)) {
                     bt = t;
-                    bi = tri;
+                    bi = r;
                 }
             }
         }
     }
+    if (bi >= 0) bi = sc.refs[bi];  // reference position -> triangle id, once per leaf
 }
 
 // Mesh::intersect (mesh.cuh:253-305), one ray start to finish.  Stack: push(sp, v) / pop(sp) on a per-lane column.

@@ -2,7 +2,7 @@
 # Developer build of libmipt with the per-phase lane-use table of the extend kernel (variants/libmipt_stats.so).
 set -e
 cd "$(dirname "$0")/../cuda_path_tracer_amd/csrc"
-F="-O3 -std=c++17 -fPIC -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt -Wno-unused-function -pthread -DMIPT_PHASE_STATS"
+F="-O3 -std=c++17 -fPIC -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt -Wno-unused-function -Wno-bitwise-instead-of-logical -pthread -DMIPT_PHASE_STATS"
 mkdir -p /tmp/ps_build ../../variants
 hipcc --offload-arch=gfx950 $F -c api.hip -o /tmp/ps_build/api.o
 hipcc --offload-arch=gfx950 $F -c wavefront.hip -o /tmp/ps_build/wavefront.o
