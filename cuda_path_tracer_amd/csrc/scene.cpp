@@ -409,11 +409,19 @@ bool HostScene::pack(int n_threads, std::string &err) {
             const size_t lc = (size_t)(k.b & kIdxMask);
             const float *l = tight + 8 * lc, *r = l + 8;
             float *rec = tpair + 16 * (((size_t)hm.node_base + lc) >> 1);
+            // stored GROWN by 2^-12 x max(|lo|, |hi|, 1), rounded outwards (see pair_culled for why that suffices); an
+            // empty box stays (+inf, -inf)
+            auto grow = [](float lo, float hi, float &glo, float &ghi) {
+                if (!(lo <= hi)) { glo = INFINITY; ghi = -INFINITY; return; }
+                const float mg = 2.44140625e-4f * std::max(std::max(std::fabs(lo), std::fabs(hi)), 1.0f);
+                glo = std::nextafter(lo - mg, -INFINITY);
+                ghi = std::nextafter(hi + mg, INFINITY);
+            };
+            const bool l_empty = !(l[0] <= l[1]) || !(l[2] <= l[3]) || !(l[4] <= l[5]);
+            const bool r_empty = !(r[0] <= r[1]) || !(r[2] <= r[3]) || !(r[4] <= r[5]);
             for (int a = 0; a < 3; a++) {
-                rec[4 * a + 0] = l[2 * a];
-                rec[4 * a + 1] = r[2 * a];
-                rec[4 * a + 2] = l[2 * a + 1];
-                rec[4 * a + 3] = r[2 * a + 1];
+                grow(l_empty ? INFINITY : l[2 * a], l_empty ? -INFINITY : l[2 * a + 1], rec[4 * a + 0], rec[4 * a + 2]);
+                grow(r_empty ? INFINITY : r[2 * a], r_empty ? -INFINITY : r[2 * a + 1], rec[4 * a + 1], rec[4 * a + 3]);
             }
         }
         int32_t *refs = reinterpret_cast<int32_t *>(A + L.refs) + hm.ref_base;

@@ -223,7 +223,12 @@ PT_HD float masked_min(const float tlo[3], const float thi[3]) {
 }
 
 // box_culled() for the two children of a node at once: their cull boxes come component-interleaved (scene_types.h),
-// so growing them and turning them into ray parameters is packed fp32 work on (left, right) pairs.
+// so turning them into ray parameters is packed fp32 work on (left, right) pairs.  The packer already grew these boxes
+// by 2^-12 x max(|lo|, |hi|, 1).  That margin covers the 1e-5 box slack, the rounding of the edge tests and the
+// rounding of the reference's P = o + d t (<= ~2.5 ulp of max(|o|, |P|) per axis) as long as |o| is within ~2000 box
+// scales; for origins farther out the hit parameter t is itself ~|o|/|d| on every axis the ray is not parallel to,
+// and the rounding of P moves the slab parameters by ~1e-7 t, which the 2^-12 (|tf| + 1) widening of the interval
+// test absorbs.  (Parallel axes: P_k = o_k exactly, the box margin alone decides.)
 PT_HD void pair_culled(f4 bx, f4 by, f4 bz, f3 o, f3 d, bool &cull_l, bool &cull_r) {
     const f4 bb[3] = {bx, by, bz};
     const float oo[3] = {o.x, o.y, o.z}, dd[3] = {d.x, d.y, d.z};
@@ -231,16 +236,12 @@ PT_HD void pair_culled(f4 bx, f4 by, f4 bz, f3 o, f3 d, bool &cull_l, bool &cull
     bool out_l = false, out_r = false;
 #pragma unroll
     for (int k = 0; k < 3; k++) {
-        const v2f lo = {bb[k].x, bb[k].y}, hi = {bb[k].z, bb[k].w};
-        const float ob = fmaxf(fabsf(oo[k]), 1.0f);
-        const v2f m = {fmaxf(fmaxf(fabsf(lo.x), fabsf(hi.x)), ob), fmaxf(fmaxf(fabsf(lo.y), fabsf(hi.y)), ob)};
-        const v2f mg = m * 2.44140625e-4f;  // (an empty box, lo = +inf > hi, only spoils its own half: see the last lines)
-        const v2f l = lo - mg, h = hi + mg;
+        const v2f l = {bb[k].x, bb[k].y}, h = {bb[k].z, bb[k].w};
         if (fabsf(dd[k]) < 1e-30f) {
             out_l |= (oo[k] < l.x) | (oo[k] > h.x);
             out_r |= (oo[k] < l.y) | (oo[k] > h.y);
         } else {
-            const float inv = __frcp_rn(dd[k]);
+            const float inv = __frcp_rn(dd[k]);  // a 1-ulp reciprocal is plenty: the test is conservative by 2^-12
             const v2f t0 = (l - oo[k]) * inv, t1 = (h - oo[k]) * inv;
             tn_l = fmax_raw(tn_l, fmin_raw(t0.x, t1.x));
             tf_l = fmin_raw(tf_l, fmax_raw(t0.x, t1.x));
@@ -248,6 +249,7 @@ PT_HD void pair_culled(f4 bx, f4 by, f4 bz, f3 o, f3 d, bool &cull_l, bool &cull
             tf_r = fmin_raw(tf_r, fmax_raw(t0.y, t1.y));
         }
     }
+    // an empty box is stored as (+inf, -inf): its own half turns into NaN / inf and is decided by the last term
     cull_l = out_l | (tn_l > tf_l + 2.44140625e-4f * (fabsf(tf_l) + 1.0f)) | !(bx.x <= bx.z);
     cull_r = out_r | (tn_r > tf_r + 2.44140625e-4f * (fabsf(tf_r) + 1.0f)) | !(bx.y <= bx.w);
 }

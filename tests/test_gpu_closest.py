@@ -84,6 +84,27 @@ def test_lattice_rays_icosphere():
     _check(desc, 1024, lattice=20)
 
 
+def test_far_origins():
+    """Origins 10^2 .. 10^6 scene sizes away, aimed at the mesh: the reference's own P = o + d t is then coarse (ulp of
+    |o|), and the conservative tests of the production kernel must still never cull what the reference accepts."""
+    desc = G.scene_icosphere_room(5)
+    s, o = _pair(desc)
+    rng = np.random.Generator(np.random.Philox(key=11))
+    n = 1 << 15
+    target = rng.uniform(-2.6, 2.6, (n, 3)).astype(np.float32) + np.array([0, -1, -2], np.float32)
+    dirs = rng.standard_normal((n, 3)).astype(np.float32)
+    dirs /= np.linalg.norm(dirs, axis=1, keepdims=True)
+    dist = (10.0 ** rng.uniform(2, 6, (n, 1))).astype(np.float32)
+    ro = (target - dirs * dist).astype(np.float32)
+    rd = (target - ro).astype(np.float32)
+    op, ot, _ = o.trace_closest(ro, rd)
+    fp, ft, _ = s.trace_closest(ro, rd)
+    _same(fp, ft, op, ot, "production kernel, far origins")
+    cp, ct, _ = s.trace_closest(ro, rd, counters=True)
+    _same(cp, ct, op, ot, "counting kernel, far origins")
+    assert (op >= 0).mean() > 0.2
+
+
 def test_forced_recheck_path(monkeypatch):
     """Every interior node flagged kRecheckBit: the children's slabs are rebuilt from their stored boxes instead of
     being derived incrementally; results must not change."""
