@@ -512,15 +512,14 @@ PT_HD float sphere_t(f3 center, float radius, f3 o, f3 d) {
     return (t2 > 0.0f) ? t2 : t1;
 }
 
-// A ray that misses the root box of every mesh (mesh.cuh:254) is decided by the spheres and planes alone.  The
-// wavefront stages that GENERATE rays run this test in their own, fully convergent lanes and answer such rays on
-// the spot, so that only rays with real traversal work reach the (divergent) extend kernel.
+// A ray that misses the root CULL box of every mesh cannot be given a mesh hit by the reference (an accepted hit lies
+// inside it, see box_culled), so it is decided by the spheres and planes alone.  The wavefront stages that GENERATE
+// rays run this cheap conservative test (no IEEE division) in their own, fully convergent lanes and answer such rays
+// on the spot, so that only rays with real traversal work reach the (divergent) extend kernel -- which applies the
+// reference's own root test (mesh.cuh:254) to the rest.
 PT_HD bool scene_trivial(const DScene &sc, f3 o, f3 d, float &out_t, int &out_prim) {
-    for (int m = 0; m < sc.n_meshes; m++) {
-        SlabBox b;
-        load_slab(sc, sc.meshes[m].root, o, d, b);
-        if (slab_hit(b, o, d) > 0.0f) return false;
-    }
+    for (int m = 0; m < sc.n_meshes; m++)
+        if (!leaf_culled(sc, sc.meshes[m].root, o, d)) return false;
     float best = -1.0f;
     int prim = -1;
     for (int i = 0; i < sc.n_spheres; i++) {
