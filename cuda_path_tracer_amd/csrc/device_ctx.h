@@ -73,7 +73,7 @@ struct DeviceCtx {
     // closest-hit work buffers
     DevBuf ray_o, ray_d, hits, io_a, io_b, io_c, io_d, counters;
     // wavefront work buffers (see wavefront.hip)
-    DevBuf wf[28];
+    DevBuf wf[32];
     EventPool events;
 };
 

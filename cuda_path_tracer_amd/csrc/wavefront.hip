@@ -108,12 +108,19 @@ struct PassParams {
 };
 
 struct WfBuffers {
-    f4 *path_o, *path_d, *path_T, *path_rad;
-    HitRec *path_hit;
-    uint32_t *path_rng, *sh_mask;
-    f4 *sh_o, *sh_d, *sh_target, *sh_contrib;
+    // Camera-path state of the paths ALIVE at a vertex, dense (index = rank in the vertex's queue) and ping-ponged by
+    // vertex parity: a path that continues writes its next state at its rank in the next vertex's arrays.  Indexing by
+    // path id instead made every vertex stream the whole pass's state through the cache no matter how few paths were
+    // left (a 128-byte line holds eight paths).  st_o.w = bits(RNG draw counter), st_d.w = bits(path id).
+    f4 *st_o[2], *st_d[2], *st_T[2];
+    HitRec *st_hit[2];
+    f4 *path_rad;        // by path id: radiance accumulated so far
+    uint32_t *path_rng;  // by path id: RNG draw counter handed from the light sub-path to the camera sub-path
+    uint32_t *sh_mask;   // by dense index of the current vertex
+    f4 *sh_o, *sh_d, *sh_target, *sh_contrib;  // [dense index * K + k]
     HitRec *sh_hit;
-    int *q_cam[2], *q_light[2], *q_shadow;  // paths alive at a vertex (stage bookkeeping) / shadow rays to trace
+    int *q_cam0;                 // bidirectional only: path ids whose camera path is traced (Q11); vertex 0 is indexed by path id
+    int *q_light[2], *q_shadow;  // light-path bookkeeping / shadow rays to trace
     int *q_ext_cam, *q_ext_light;           // the subset of camera / light rays that needs the extend kernel
     int *counts;                 // per-stage queue counts of the current pass
     unsigned long long *totals;  // [0] camera rays [1] shadow rays [2] light rays [3] rays traced by k_extend
@@ -153,16 +160,16 @@ __global__ __launch_bounds__(kBlock) void k_raygen(DScene sc, PassParams pp, WfB
         const float jx = rng.u();  // Q18: first draw -> X, second -> Y
         const float jy = rng.u();
         dir = norm3(camera_dir(sc, (float)col + jx, (float)row + jy, pp.W, pp.H));
-        b.path_o[pid] = mk4(ld3(sc.cam_eye), 0.f);
-        b.path_d[pid] = mk4(dir, 0.f);
-        b.path_T[pid] = f4{1.f, 1.f, 1.f, 1.f};
+        b.st_o[0][pid] = mk4(ld3(sc.cam_eye), as_f32(rng.draw));  // vertex 0: dense index == path id
+        b.st_d[0][pid] = mk4(dir, as_f32((uint32_t)pid));
+        b.st_T[0][pid] = f4{1.f, 1.f, 1.f, 1.f};
         b.path_rad[pid] = f4{0.f, 0.f, 0.f, 0.f};
-        b.path_rng[pid] = rng.draw;
-        b.sh_mask[pid] = 0u;
-        if (pp.Dl == 0) b.q_cam[0][pid] = pid;
-        else b.q_light[0][pid] = pid;
+        if (pp.Dl != 0) {
+            b.path_rng[pid] = rng.draw;
+            b.q_light[0][pid] = pid;
+        }
     }
-    (void)emit_ray(sc, live, ld3(sc.cam_eye), dir, live ? &b.path_hit[pid] : nullptr, pid, b.q_ext_cam,
+    (void)emit_ray(sc, live, ld3(sc.cam_eye), dir, live ? &b.st_hit[0][pid] : nullptr, pid, b.q_ext_cam,
                    &b.counts[kCntPad * (kCntExtCam + 0)], ap_lds, phase);
 }
 
@@ -270,7 +277,7 @@ __global__ __launch_bounds__(kBlock) void k_light_shade(DScene sc, PassParams pp
                        &b.counts[kCntPad * (kCntExtLight + i + 1)], ap_lds, phase);
         if (i == 0) {
             const int ci = block_append(to_cam, &b.counts[kCntPad * (kCntCam + 0)], ap_lds, phase);
-            if (to_cam) b.q_cam[0][ci] = pid;
+            if (to_cam) b.q_cam0[ci] = pid;
         }
     }
 }
@@ -281,21 +288,25 @@ __global__ __launch_bounds__(kBlock) void k_shade(DScene sc, PassParams pp, WfBu
     int phase = 0;
     int n_trivial = 0;  // shadow rays answered here; one atomic per wave at the end
     const int n = b.counts[kCntPad * (kCntCam + i)];
-    const int *qin = b.q_cam[i & 1];
-    int *qout = b.q_cam[(i + 1) & 1];
+    const int par = i & 1;
+    const bool by_id = (i == 0) && (pp.Dl != 0);  // bidirectional vertex 0: the alive set is a list of path ids
     for (int base = blockIdx.x * kBlock; base < n; base += gridDim.x * kBlock) {
         const int idx = base + threadIdx.x;
         bool cont = false;
-        int pid = -1;
-        uint32_t mask = 0u;
+        int pid = -1, j = 0;
+        uint32_t mask = 0u, draw = 0u;
         f3 nro = mk3(0.f, 0.f, 0.f), nrd = mk3(0.f, 0.f, 1.f);  // the next camera ray, when the path continues
+        f3 Tc = mk3(0.f, 0.f, 0.f);
+        float pc = 1.0f;
         if (idx < n) {
-            pid = qin[idx];
-            const HitRec h = b.path_hit[pid];
-            const f3 o = xyz(b.path_o[pid]), d = xyz(b.path_d[pid]);
-            const f4 Tp = b.path_T[pid];
-            f3 Tc = xyz(Tp);
-            float pc = Tp.w;
+            j = by_id ? b.q_cam0[idx] : idx;
+            const HitRec h = b.st_hit[par][j];
+            const f4 o4 = b.st_o[par][j], d4 = b.st_d[par][j];
+            const f3 o = xyz(o4), d = xyz(d4);
+            pid = (int)as_u32(d4.w);
+            const f4 Tp = b.st_T[par][j];
+            Tc = xyz(Tp);
+            pc = Tp.w;
             if (h.prim < 0) {
                 if (pp.use_env) {  // build-defined extension: radiance of the cube map on a miss
                     f4 r = b.path_rad[pid];
@@ -305,7 +316,7 @@ __global__ __launch_bounds__(kBlock) void k_shade(DScene sc, PassParams pp, WfBu
                 }
             } else {
                 const Surface s = surface_at(sc, o, d, h.t, h.prim);
-                const size_t sbase = (size_t)pid * pp.K;
+                const size_t sbase = (size_t)j * pp.K;
                 {  // direct connection to lights[0] (Q13); the shadow ray starts AT the light (Q10)
                     const f3 lp = xyz(sc.lights[0]);
                     const f3 ld = norm3(s.pos - lp);
@@ -321,8 +332,8 @@ __global__ __launch_bounds__(kBlock) void k_shade(DScene sc, PassParams pp, WfBu
                         mask |= 1u;
                     }
                 }
-                for (int j = 0; j < pp.Dl; j++) {  // connections to the stored light vertices (Q15, no MIS)
-                    const size_t vi = (size_t)pid * pp.Dl + j;
+                for (int jj = 0; jj < pp.Dl; jj++) {  // connections to the stored light vertices (Q15, no MIS)
+                    const size_t vi = (size_t)pid * pp.Dl + jj;
                     const f4 lp4 = b.lv_pos[vi];
                     if (lp4.w < 0.0f) break;
                     const f3 LT = xyz(b.lv_T[vi]);
@@ -337,17 +348,18 @@ __global__ __launch_bounds__(kBlock) void k_shade(DScene sc, PassParams pp, WfBu
                     const f3 cw = Tc * brdf * cc / pc;
                     const f3 lw = LT / ln4.w;
                     const f3 contrib = lw * G * cw;
-                    const size_t si = sbase + 1 + j;
+                    const size_t si = sbase + 1 + jj;
                     b.sh_o[si] = mk4(s.pos + s.nrm * kEps, 0.f);
                     b.sh_d[si] = mk4(norm3(dir), 0.f);
                     b.sh_target[si] = mk4(xyz(lp4), 1.f);
                     b.sh_contrib[si] = mk4(contrib, 0.f);
-                    mask |= 1u << (1 + j);
+                    mask |= 1u << (1 + jj);
                 }
                 if (i + 1 < pp.Dc) {  // next vertex (Q16); nothing downstream reads it after the last vertex
                     const int slot = pid / pp.npix, pixel = pid - slot * pp.npix;
                     Rng rng;
-                    rng.init(pp.seed, (uint32_t)pixel, (uint32_t)(pp.sample0 + slot * pp.sample_stride), b.path_rng[pid]);
+                    rng.init(pp.seed, (uint32_t)pixel, (uint32_t)(pp.sample0 + slot * pp.sample_stride),
+                             by_id ? b.path_rng[pid] : as_u32(o4.w));
                     const float pd = avg3(s.kd), pm = avg3(s.ks);
                     const float rnd = rng.u();
                     f3 od;
@@ -365,25 +377,27 @@ __global__ __launch_bounds__(kBlock) void k_shade(DScene sc, PassParams pp, WfBu
                         pc = pc * pdf * pm;
                         cont = true;
                     }
-                    b.path_rng[pid] = rng.draw;
+                    draw = rng.draw;
                     if (cont) {
                         nro = s.pos + s.nrm * kEps;
                         nrd = norm3(od);
-                        b.path_o[pid] = mk4(nro, 0.f);
-                        b.path_d[pid] = mk4(nrd, 0.f);
-                        b.path_T[pid] = mk4(Tc, pc);
                     }
                 }
             }
-            b.sh_mask[pid] = mask;
+            b.sh_mask[j] = mask;
         }
+        // a continuing path takes its rank among the block's continuing paths as its index at the next vertex
         const int qi = block_append(cont, &b.counts[kCntPad * (kCntCam + i + 1)], ap_lds, phase);
-        if (cont) qout[qi] = pid;
-        (void)emit_ray(sc, cont, nro, nrd, cont ? &b.path_hit[pid] : nullptr, pid, b.q_ext_cam,
+        if (cont) {
+            b.st_o[par ^ 1][qi] = mk4(nro, as_f32(draw));
+            b.st_d[par ^ 1][qi] = mk4(nrd, as_f32((uint32_t)pid));
+            b.st_T[par ^ 1][qi] = mk4(Tc, pc);
+        }
+        (void)emit_ray(sc, cont, nro, nrd, cont ? &b.st_hit[par ^ 1][qi] : nullptr, qi, b.q_ext_cam,
                        &b.counts[kCntPad * (kCntExtCam + i + 1)], ap_lds, phase);
         for (int k = 0; k < pp.K; k++) {  // batched shadow rays: one append per slot kind keeps waves converged
             const bool emit = (mask >> k) & 1u;
-            const size_t si = emit ? (size_t)pid * pp.K + k : 0;
+            const size_t si = emit ? (size_t)j * pp.K + k : 0;
             const f3 so = emit ? xyz(b.sh_o[si]) : nro, sd = emit ? xyz(b.sh_d[si]) : nrd;
             if (emit_ray(sc, emit, so, sd, emit ? &b.sh_hit[si] : nullptr, (int)si, b.q_shadow,
                          &b.counts[kCntPad * (kCntShadow + i)], ap_lds, phase))
@@ -397,15 +411,17 @@ __global__ __launch_bounds__(kBlock) void k_shade(DScene sc, PassParams pp, WfBu
 // visibility + accumulation for vertex i (kernel.cu:249-256, 268-279)
 __global__ __launch_bounds__(kBlock) void k_resolve(PassParams pp, WfBuffers b, int i) {
     const int n = b.counts[kCntPad * (kCntCam + i)];
-    const int *qin = b.q_cam[i & 1];
+    const int par = i & 1;
+    const bool by_id = (i == 0) && (pp.Dl != 0);
     for (int idx = blockIdx.x * kBlock + threadIdx.x; idx < n; idx += gridDim.x * kBlock) {
-        const int pid = qin[idx];
-        const uint32_t mask = b.sh_mask[pid];
+        const int j = by_id ? b.q_cam0[idx] : idx;
+        const uint32_t mask = b.sh_mask[j];
         if (mask == 0u) continue;
+        const int pid = (int)as_u32(b.st_d[par][j].w);
         f4 r = b.path_rad[pid];
         for (int k = 0; k < pp.K; k++) {
             if (!((mask >> k) & 1u)) continue;
-            const size_t si = (size_t)pid * pp.K + k;
+            const size_t si = (size_t)j * pp.K + k;
             const HitRec h = b.sh_hit[si];
             const f4 tg = b.sh_target[si];
             const f3 P = xyz(b.sh_o[si]) + xyz(b.sh_d[si]) * h.t;
@@ -505,38 +521,40 @@ int wavefront_render(const HostScene &hs, DeviceCtx &dc, const mipt_render_confi
     S = (int)std::min<int64_t>(std::min<int64_t>(S, n_samples), std::max<int64_t>(1, ((int64_t)1 << 28) / ((int64_t)npix * K)));
     const size_t P = (size_t)S * npix;
 
-    size_t sizes[28] = {0};
-    sizes[0] = sizes[1] = sizes[3] = sizes[4] = P * sizeof(f4);
-    sizes[2] = P * sizeof(HitRec);
-    sizes[5] = sizes[11] = P * 4;
-    sizes[6] = sizes[7] = sizes[8] = sizes[9] = P * K * sizeof(f4);
-    sizes[10] = P * K * sizeof(HitRec);
-    sizes[12] = sizes[13] = P * 4;
-    sizes[14] = P * K * 4;
-    sizes[25] = P * 4;
-    sizes[17] = (size_t)kCntTotal * kCntPad * 4 + 64;
+    size_t sizes[32] = {0};
+    for (int k = 0; k < 6; k++) sizes[k] = P * sizeof(f4);         // st_o[2], st_d[2], st_T[2]
+    sizes[6] = sizes[7] = P * sizeof(HitRec);                       // st_hit[2]
+    sizes[8] = P * sizeof(f4);                                      // path_rad
+    sizes[9] = P * 4;                                               // sh_mask
+    sizes[10] = sizes[11] = sizes[12] = sizes[13] = P * K * sizeof(f4);  // sh_o, sh_d, sh_target, sh_contrib
+    sizes[14] = P * K * sizeof(HitRec);                             // sh_hit
+    sizes[15] = P * K * 4;                                          // q_shadow
+    sizes[16] = P * 4;                                              // q_ext_cam
+    sizes[17] = (size_t)kCntTotal * kCntPad * 4 + 64;               // counts + totals
     if (Dl > 0) {
-        sizes[15] = sizes[16] = sizes[26] = P * 4;
-        sizes[18] = sizes[19] = sizes[20] = P * Dl * sizeof(f4);
-        sizes[21] = sizes[22] = sizes[24] = P * sizeof(f4);
-        sizes[23] = P * sizeof(HitRec);
+        sizes[18] = sizes[19] = sizes[20] = P * Dl * sizeof(f4);    // lv_pos, lv_nrm, lv_T
+        sizes[21] = sizes[22] = sizes[24] = P * sizeof(f4);         // l_o, l_d, l_state
+        sizes[23] = P * sizeof(HitRec);                             // l_hit
+        sizes[25] = sizes[26] = sizes[27] = sizes[28] = sizes[29] = P * 4;  // path_rng, q_cam0, q_light[2], q_ext_light
     }
-    static_assert(sizeof(dc.wf) / sizeof(dc.wf[0]) >= 27, "wf buffer table too small");
-    for (int i = 0; i < 27; i++)
+    static_assert(sizeof(dc.wf) / sizeof(dc.wf[0]) >= 30, "wf buffer table too small");
+    for (int i = 0; i < 30; i++)
         if (sizes[i]) WF_TRY(dc.wf[i].reserve(sizes[i]));
     WfBuffers b;
     memset(&b, 0, sizeof(b));
-    b.path_o = dc.wf[0].as<f4>(); b.path_d = dc.wf[1].as<f4>(); b.path_hit = dc.wf[2].as<HitRec>();
-    b.path_T = dc.wf[3].as<f4>(); b.path_rad = dc.wf[4].as<f4>(); b.path_rng = dc.wf[5].as<uint32_t>();
-    b.sh_o = dc.wf[6].as<f4>(); b.sh_d = dc.wf[7].as<f4>(); b.sh_target = dc.wf[8].as<f4>(); b.sh_contrib = dc.wf[9].as<f4>();
-    b.sh_hit = dc.wf[10].as<HitRec>(); b.sh_mask = dc.wf[11].as<uint32_t>();
-    b.q_cam[0] = dc.wf[12].as<int>(); b.q_cam[1] = dc.wf[13].as<int>(); b.q_shadow = dc.wf[14].as<int>();
-    b.q_light[0] = dc.wf[15].as<int>(); b.q_light[1] = dc.wf[16].as<int>();
-    b.q_ext_cam = dc.wf[25].as<int>(); b.q_ext_light = dc.wf[26].as<int>();
+    for (int k = 0; k < 2; k++) {
+        b.st_o[k] = dc.wf[k].as<f4>(); b.st_d[k] = dc.wf[2 + k].as<f4>(); b.st_T[k] = dc.wf[4 + k].as<f4>();
+        b.st_hit[k] = dc.wf[6 + k].as<HitRec>();
+    }
+    b.path_rad = dc.wf[8].as<f4>(); b.sh_mask = dc.wf[9].as<uint32_t>();
+    b.sh_o = dc.wf[10].as<f4>(); b.sh_d = dc.wf[11].as<f4>(); b.sh_target = dc.wf[12].as<f4>(); b.sh_contrib = dc.wf[13].as<f4>();
+    b.sh_hit = dc.wf[14].as<HitRec>(); b.q_shadow = dc.wf[15].as<int>(); b.q_ext_cam = dc.wf[16].as<int>();
     b.counts = dc.wf[17].as<int>();
     b.totals = reinterpret_cast<unsigned long long *>(dc.wf[17].as<char>() + (size_t)kCntTotal * kCntPad * 4 + 8);
     b.lv_pos = dc.wf[18].as<f4>(); b.lv_nrm = dc.wf[19].as<f4>(); b.lv_T = dc.wf[20].as<f4>();
     b.l_o = dc.wf[21].as<f4>(); b.l_d = dc.wf[22].as<f4>(); b.l_hit = dc.wf[23].as<HitRec>(); b.l_state = dc.wf[24].as<f4>();
+    b.path_rng = dc.wf[25].as<uint32_t>(); b.q_cam0 = dc.wf[26].as<int>();
+    b.q_light[0] = dc.wf[27].as<int>(); b.q_light[1] = dc.wf[28].as<int>(); b.q_ext_light = dc.wf[29].as<int>();
 
     dc.events.reset();
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ext_ev;
@@ -578,7 +596,7 @@ int wavefront_render(const HostScene &hs, DeviceCtx &dc, const mipt_render_confi
             }
         }
         for (int i = 0; i < Dc; i++) {
-            extend(b.path_o, b.path_d, b.q_ext_cam, &b.counts[kCntPad * (kCntExtCam + i)], b.path_hit, np);
+            extend(b.st_o[i & 1], b.st_d[i & 1], b.q_ext_cam, &b.counts[kCntPad * (kCntExtCam + i)], b.st_hit[i & 1], np);
             hipLaunchKernelGGL(k_shade, dim3(path_grid), dim3(kBlock), 0, sm, dc.view, pp, b, i);
             extend(b.sh_o, b.sh_d, b.q_shadow, &b.counts[kCntPad * (kCntShadow + i)], b.sh_hit, np * K);
             hipLaunchKernelGGL(k_resolve, dim3(path_grid), dim3(kBlock), 0, sm, pp, b, i);
