@@ -70,6 +70,9 @@ def closest_hit_bench(torch, G, Scene, FLAG_COUNTERS, n_rays, with_cpu):
             st = s.trace_closest_device(d_o.data_ptr(), d_d.data_ptr(), n_rays, d_p.data_ptr(), d_t.data_ptr())
             ms_ext.append(st["ms_extend"])
             ms_all.append(st["ms_total"])
+        n_cpu = min(n_rays, 1 << 20)
+        gp = d_p[:n_cpu].cpu().numpy()  # results of the timed (production) kernel, before the counting run overwrites them
+        gt = d_t[:n_cpu].cpu().numpy()
         n_ctr = min(n_rays, 1 << 22)
         sc = s.trace_closest_device(d_o.data_ptr(), d_d.data_ptr(), n_ctr, d_p.data_ptr(), d_t.data_ptr(), counters=True)
         hit_frac = sc["ctr_hits"] / n_ctr
@@ -83,16 +86,14 @@ def closest_hit_bench(torch, G, Scene, FLAG_COUNTERS, n_rays, with_cpu):
             "per_ray": {k: round(v, 2) for k, v in means.items()}, "hit_frac": round(hit_frac, 4),
             "culled_candidate_frac": round(sc["ctr_culled"] / max(1, sc["ctr_tris"]), 4),
             "bytes_per_ray": round(bpr, 1),
+            "reference_layout_bytes_per_ray": round(80 * means["nodes"] + 72 * means["tris"], 1),
             "roofline": {"bound": "hbm", "achieved": round(bpr * n_rays / (ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(bpr * n_rays / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": None},
         }
         if orc is not None:
-            n_cpu = 1 << 17
             t0 = time.time()
             op, ot, oc = orc.trace_closest(ro[:n_cpu], rd[:n_cpu])
             dt = time.time() - t0
-            gp = d_p[:n_cpu].cpu().numpy()
-            gt = d_t[:n_cpu].cpu().numpy()
             rec["cpu_oracle"] = {"Mrays_per_s": round(n_cpu / dt / 1e6, 3), "cores": cpu_threads(), "rays": n_cpu,
                                  "parity_prim_mismatches": int((gp != op).sum()),
                                  "parity_t_bit_mismatches": int((gt.view(np.uint32) != ot.view(np.uint32)).sum())}
@@ -200,7 +201,9 @@ def main():
             "image_mean": round(img_mean, 6),
             "roofline": {"bound": "hbm", "kernel": "k_extend", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-                         "bytes_per_ray": round(bpr, 1), "per_ray": {k: round(v, 2) for k, v in means.items()},
+                         "bytes_per_ray": round(bpr, 1),
+                         "reference_layout_bytes_per_ray": round(80 * means["nodes"] + 72 * means["tris"], 1),
+                         "per_ray": {k: round(v, 2) for k, v in means.items()},
                          "launches": tot["extend_launches"],
                          "avg_launch_ms": round(tot["ms_extend"] / max(1, tot["extend_launches"]), 4),
                          "rays_per_launch": round(tot["rays_extended"] / max(1, tot["extend_launches"])),
