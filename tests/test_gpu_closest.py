@@ -84,6 +84,10 @@ def test_lattice_rays_icosphere():
     _check(desc, 1024, lattice=20)
 
 
+def test_overlapping_meshes():
+    _check(G.scene_multi_sphere(4), 16384, lattice=8)
+
+
 def test_far_origins():
     """Origins 10^2 .. 10^6 scene sizes away, aimed at the mesh: the reference's own P = o + d t is then coarse (ulp of
     |o|), and the conservative tests of the production kernel must still never cull what the reference accepts."""

@@ -101,3 +101,24 @@ def test_env_lookup_matches_oracle():
     axes = np.array([[1, 0, 0], [-1, 0, 0], [0, 1, 0], [0, -1, 0], [0, 0, 1], [0, 0, -1]], np.float32)
     dirs = np.concatenate([dirs, corners, edges, axes])
     assert np.array_equal(s.env_lookup(dirs), o.env_lookup(dirs))
+
+
+def test_overlapping_meshes_simple_and_bidirectional():
+    # the C5 layout at a small subdivision level: eight mutually overlapping kd meshes tested linearly (kernel.cu:147-150)
+    s, o = _pair(G.scene_multi_sphere(3))
+    for kw in (dict(cam_depth=5, light_depth=0), dict(cam_depth=3, light_depth=3)):
+        cfg = make_config(72, 48, spp=3, **kw)
+        img, _ = s.render(cfg)
+        ref, _ = o.render(cfg)
+        assert ref.max() > 0.01
+        assert np.array_equal(img.view(np.uint32), ref.view(np.uint32)), (kw, np.abs(img - ref).max())
+
+
+def test_deep_paths_many_passes():
+    # depth 16 (the accepted maximum) and a pass size that does not divide the sample count
+    s, o = _pair(G.scene_icosphere_room(3))
+    cfg = make_config(40, 30, spp=7, cam_depth=16, light_depth=0, samples_per_pass=3)
+    img, st = s.render(cfg)
+    ref, _ = o.render(cfg)
+    assert np.array_equal(img.view(np.uint32), ref.view(np.uint32))
+    assert st["samples"] == 40 * 30 * 7
