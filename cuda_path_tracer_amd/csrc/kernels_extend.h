@@ -148,6 +148,9 @@ __global__ __launch_bounds__(kExtendBlock, 5) void k_extend(DScene sc, const f4 
             continue;
         }
         // ---- open the next mesh: root box test (mesh.cuh:254) -------------------------------------------------
+        if (!COUNT && has_ray && start_mesh) {  // meshes whose root cull box the ray misses cannot be hit: skip them cheaply
+            while (m < sc.n_meshes && leaf_culled(sc, sc.meshes[m].root, o, d)) m++;
+        }
         if (has_ray && start_mesh && m < sc.n_meshes) {
             PSTAT(ps, 3);
             node = sc.meshes[m].root;
@@ -156,9 +159,9 @@ __global__ __launch_bounds__(kExtendBlock, 5) void k_extend(DScene sc, const f4 
             bool enter;
             if (COUNT) {
                 enter = slab_hit(cur, o, d) > 0.0f;
-            } else {  // a mesh whose root cull box the ray misses cannot be hit: same outcome as walking it in vain
+            } else {
                 mask_slab(cur, o, d);
-                enter = (masked_min(cur.tlo, cur.thi) > 0.0f) && !leaf_culled(sc, node, o, d);
+                enter = masked_min(cur.tlo, cur.thi) > 0.0f;
             }
             if (enter) {
                 sp = 0;
