@@ -148,10 +148,20 @@ __global__ __launch_bounds__(kExtendBlock, 5) void k_extend(DScene sc, const f4 
             continue;
         }
         // ---- open the next mesh: root box test (mesh.cuh:254) -------------------------------------------------
-        if (!COUNT && has_ray && start_mesh) {  // meshes whose root cull box the ray misses cannot be hit: skip them cheaply
-            while (m < sc.n_meshes && leaf_culled(sc, sc.meshes[m].root, o, d)) m++;
+        // a mesh whose root cull box the ray misses cannot be hit: skipped before any exact slab arithmetic
+        bool skip_mesh = false;
+        if (!COUNT && has_ray && start_mesh) {
+            // (bounded: lanes in other states wait meanwhile; with few meshes one try per round measured faster --
+            //  default scene, 3 meshes: 523 vs 433 Msamples/s bidirectional; 8 meshes: 49 vs 54 the other way)
+            const int max_tries = sc.n_meshes > 4 ? 4 : 1;
+#pragma unroll 1
+            for (int tries = 0; tries < max_tries && m < sc.n_meshes; tries++) {
+                skip_mesh = leaf_culled(sc, sc.meshes[m].root, o, d);
+                if (!skip_mesh) break;
+                m++;
+            }
         }
-        if (has_ray && start_mesh && m < sc.n_meshes) {
+        if (has_ray && start_mesh && !skip_mesh && m < sc.n_meshes) {
             PSTAT(ps, 3);
             node = sc.meshes[m].root;
             nd = sc.nodes[node];
