@@ -219,6 +219,12 @@ def main():
                 line["roofline"]["traffic_unit"] = "bytes per launch (TCC FETCH_SIZE + WRITE_SIZE, raw)"
                 line["roofline"]["traffic_source"] = "profiles/r1_pmc_bench_c2.json"
                 line["roofline"]["algorithmic_bytes_per_launch"] = round(bpr * tot["rays_extended"] / max(1, tot["extend_launches"]))
+                pm = json.load(open(pmc_path))
+                # what actually bounds the kernel: VALU issue.  busy = 4 cycles per wave64 VALU instruction
+                # over the kernel's cycles on 1024 SIMDs (GRBM_GUI_ACTIVE is summed over the 8 XCDs)
+                line["roofline"]["valu_busy_frac"] = round(4.0 * pm["SQ_ACTIVE_INST_VALU"]["mean_per_launch"]
+                                                           / (pm["GRBM_GUI_ACTIVE"]["mean_per_launch"] / 8.0 * 1024.0), 3)
+                line["roofline"]["valu_lane_use"] = round(pm["valu_lane_utilisation"], 3)
             except (KeyError, ValueError):
                 pass
         if not args.no_cpu_baseline and world == 1:
