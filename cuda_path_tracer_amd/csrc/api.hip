@@ -241,8 +241,8 @@ int mipt_trace_closest_device(mipt_scene *s, int slot, const float *d_ray_o, con
     HIP_TRY(hipMemsetAsync(dc.counters.p, 0, 512, dc.stream));
     const int blocks = (int)((n + 255) / 256);
     HIP_TRY(hipEventRecord(e0, dc.stream));
-    hipLaunchKernelGGL(k_make_rays, dim3(blocks), dim3(256), 0, dc.stream, d_ray_o, d_ray_d, n, dc.ray_o.as<f4>(),
-                       dc.ray_d.as<f4>());
+    hipLaunchKernelGGL(k_make_rays, dim3(blocks), dim3(256), 0, dc.stream, dc.view, d_ray_o, d_ray_d, n, dc.ray_o.as<f4>(),
+                       dc.ray_d.as<f4>(), dc.hits.as<HitRec>());
     HIP_TRY(hipEventRecord(e1, dc.stream));
     launch_extend(dc, count, dc.ray_o.as<f4>(), dc.ray_d.as<f4>(), nullptr, nullptr, (int)n, n, dc.hits.as<HitRec>(),
                   reinterpret_cast<int *>(dc.counters.as<char>() + 64), dc.counters.as<unsigned long long>());

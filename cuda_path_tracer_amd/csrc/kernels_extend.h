@@ -92,7 +92,7 @@ __global__ __launch_bounds__(kExtendBlock, 5) void k_extend(DScene sc, const f4 
         PSTAT(ps, 0);
         // ---- rays that ran out of meshes: Scene::firstIntersect's result (kernel.cu:145-160) ------------------
         if (has_ray && start_mesh && m >= sc.n_meshes) {
-            // spheres/planes were evaluated at fetch time; a mesh hit wins ties because meshes come first
+            // spheres/planes were evaluated when the ray was made; a mesh hit wins ties because meshes come first
             PSTAT(ps, 1);
             const bool mesh_wins = (best > 0.0f) && (q_t < 0.0f || best <= q_t);
             HitRec h;
@@ -122,17 +122,10 @@ __global__ __launch_bounds__(kExtendBlock, 5) void k_extend(DScene sc, const f4 
                     d = mk3(d4.x, d4.y, d4.z);
                     best = -1.0f;
                     prim = -1;
-                    q_t = -1.0f;
-                    q_prim = -1;
-                    for (int i = 0; i < sc.n_spheres; i++) {  // kernel.cu:151-154
-                        const f4 sp4 = sc.spheres[2 * i];
-                        const float t = sphere_t(mk3(sp4.x, sp4.y, sp4.z), sp4.w, o, d);
-                        if (t > 0.0f && (q_t < 0.0f || t < q_t)) { q_t = t; q_prim = sc.total_tris + i; }
-                    }
-                    for (int i = 0; i < sc.n_planes; i++) {   // kernel.cu:155-158
-                        const f4 p = sc.planes[2 * i], pn = sc.planes[2 * i + 1];
-                        const float t = plane_t(mk3(p.x, p.y, p.z), mk3(pn.x, pn.y, pn.z), o, d);
-                        if (t > 0.0f && (q_t < 0.0f || t < q_t)) { q_t = t; q_prim = sc.total_tris + sc.n_spheres + i; }
+                    {  // the sphere / plane answer parked in the hit slot by the stage that made the ray (kernel.cu:151-158)
+                        const HitRec q = hits[slot];
+                        q_t = q.t;
+                        q_prim = q.prim;
                     }
                     m = 0;
                     start_mesh = true;
@@ -282,15 +275,20 @@ __global__ __launch_bounds__(kExtendBlock) void k_extend_simple(DScene sc, const
     if (COUNT) flush_counters(tc, hit_tris, ctr);
 }
 
-// Ray(o, d) constructor (ray.cuh:10): dir = d * (1/(|d|+eps)).  Packed xyz triples -> float4 pairs.
-static __global__ __launch_bounds__(256) void k_make_rays(const float *__restrict__ o3, const float *__restrict__ d3,
-                                                          int64_t n, f4 *__restrict__ ray_o, f4 *__restrict__ ray_d) {
+// Ray(o, d) constructor (ray.cuh:10): dir = d * (1/(|d|+eps)).  Packed xyz triples -> float4 pairs; the sphere / plane
+// answer of each ray is parked in its hit slot (see quadrics_closest).
+static __global__ __launch_bounds__(256) void k_make_rays(DScene sc, const float *__restrict__ o3, const float *__restrict__ d3,
+                                                          int64_t n, f4 *__restrict__ ray_o, f4 *__restrict__ ray_d,
+                                                          HitRec *__restrict__ hits) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     const f3 o = mk3(o3[3 * i], o3[3 * i + 1], o3[3 * i + 2]);
     const f3 d = norm3(mk3(d3[3 * i], d3[3 * i + 1], d3[3 * i + 2]));
     ray_o[i] = f4{o.x, o.y, o.z, 0.f};
     ray_d[i] = f4{d.x, d.y, d.z, 0.f};
+    HitRec h;
+    quadrics_closest(sc, o, d, h.t, h.prim);
+    hits[i] = h;
 }
 
 static __global__ __launch_bounds__(256) void k_split_hits(const HitRec *__restrict__ hits, int64_t n,

@@ -512,14 +512,10 @@ PT_HD float sphere_t(f3 center, float radius, f3 o, f3 d) {
     return (t2 > 0.0f) ? t2 : t1;
 }
 
-// A ray that misses the root CULL box of every mesh cannot be given a mesh hit by the reference (an accepted hit lies
-// inside it, see box_culled), so it is decided by the spheres and planes alone.  The wavefront stages that GENERATE
-// rays run this cheap conservative test (no IEEE division) in their own, fully convergent lanes and answer such rays
-// on the spot, so that only rays with real traversal work reach the (divergent) extend kernel -- which applies the
-// reference's own root test (mesh.cuh:254) to the rest.
-PT_HD bool scene_trivial(const DScene &sc, f3 o, f3 d, float &out_t, int &out_prim) {
-    for (int m = 0; m < sc.n_meshes; m++)
-        if (!leaf_culled(sc, sc.meshes[m].root, o, d)) return false;
+// The sphere / plane part of Scene::firstIntersect (kernel.cu:151-158): closest of them, strict '<' keeps the earlier.
+// Evaluated for every ray by the stage that GENERATES it (convergent lanes) and parked in the ray's hit slot; the
+// extend kernel starts from that answer and only adds the meshes (a mesh hit wins ties: meshes come first).
+PT_HD void quadrics_closest(const DScene &sc, f3 o, f3 d, float &out_t, int &out_prim) {
     float best = -1.0f;
     int prim = -1;
     for (int i = 0; i < sc.n_spheres; i++) {
@@ -534,6 +530,13 @@ PT_HD bool scene_trivial(const DScene &sc, f3 o, f3 d, float &out_t, int &out_pr
     }
     out_t = best;
     out_prim = prim;
+}
+// A ray that misses the root CULL box of every mesh cannot be given a mesh hit by the reference (an accepted hit lies
+// inside it, see box_culled): the parked sphere / plane answer is final and the ray never reaches the (divergent)
+// extend kernel -- which applies the reference's own root test (mesh.cuh:254) to the rest.  No IEEE division here.
+PT_HD bool misses_every_mesh(const DScene &sc, f3 o, f3 d) {
+    for (int m = 0; m < sc.n_meshes; m++)
+        if (!leaf_culled(sc, sc.meshes[m].root, o, d)) return false;
     return true;
 }
 

@@ -74,22 +74,17 @@ __device__ __forceinline__ int wave_sum_i(int v) {
     return v;
 }
 
-// Answer a freshly generated ray on the spot if it is trivial (see scene_trivial), else queue it for extend.
-// Call it from block-convergent code.  Returns true when the ray was answered here (callers tally those).
+// Park the sphere / plane answer of a freshly generated ray in its hit slot; if the ray misses every mesh's root cull
+// box that answer is final, else queue the ray for extend.  Call it from block-convergent code.  Returns true when the
+// ray was decided here (callers tally those).
 __device__ __forceinline__ bool emit_ray(const DScene &sc, bool valid, f3 o, f3 d, HitRec *hit_slot, int queue_value, int *queue,
                                          int *queue_count, int *lds, int &phase) {
     bool need_extend = false;
     if (valid) {
-        float t;
-        int prim;
-        if (scene_trivial(sc, o, d, t, prim)) {
-            HitRec h;
-            h.t = t;
-            h.prim = prim;
-            *hit_slot = h;
-        } else {
-            need_extend = true;
-        }
+        HitRec h;
+        quadrics_closest(sc, o, d, h.t, h.prim);
+        *hit_slot = h;
+        need_extend = !misses_every_mesh(sc, o, d);
     }
     const int qi = block_append(need_extend, queue_count, lds, phase);
     if (need_extend) queue[qi] = queue_value;
