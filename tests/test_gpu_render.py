@@ -122,3 +122,24 @@ def test_deep_paths_many_passes():
     ref, _ = o.render(cfg)
     assert np.array_equal(img.view(np.uint32), ref.view(np.uint32))
     assert st["samples"] == 40 * 30 * 7
+
+
+def test_scene_without_meshes():
+    # planes and spheres only: every ray is decided by the stage that generates it, the extend kernel gets empty queues
+    desc = G.scene_icosphere_room(2)
+    desc.meshes.clear()
+    desc.materials.append(((0.1, 0.1, 0.1), (0.8, 0.8, 0.8)))
+    desc.spheres.append(((-1.0, -3.0, -2.0), 1.5, len(desc.materials) - 1))
+    desc.spheres.append(((2.0, -4.0, -3.0), 1.0, 0))
+    s, o = _pair(desc)
+    for kw in (dict(cam_depth=6, light_depth=0), dict(cam_depth=3, light_depth=3)):
+        cfg = make_config(64, 48, spp=3, **kw)
+        img, st = s.render(cfg)
+        ref, _ = o.render(cfg)
+        assert ref.max() > 0.01
+        assert np.array_equal(img.view(np.uint32), ref.view(np.uint32)), (kw, np.abs(img - ref).max())
+        assert st["rays_extended"] == 0 and st["rays_total"] > 0
+    ro, rd = G.incoherent_rays(4096, (-3, -4, -4), (3, 0, 0))
+    gp, gt, _ = s.trace_closest(ro, rd)
+    op, ot, _ = o.trace_closest(ro, rd)
+    assert np.array_equal(gp, op) and np.array_equal(gt.view(np.uint32), ot.view(np.uint32))
