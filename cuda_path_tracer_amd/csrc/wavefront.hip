@@ -100,7 +100,22 @@ struct PassParams {
     int Dc, Dl, K;       // camera depth, light depth, shadow slots per path (1 + Dl)
     int use_env;
     uint32_t seed;
+    int tiles_x;         // > 0: paths of a sample are laid out in 8x8 pixel tiles (W and H multiples of 8), else row-major
 };
+
+// Position of a path inside its sample slot <-> pixel.  64 consecutive paths (one wave of primary rays, and what the
+// queues keep together afterwards) cover an 8x8 tile instead of a 64x1 strip: +6..10 % on primary-ray traversal.
+__device__ __forceinline__ int pixel_of(const PassParams &pp, int p) {
+    if (pp.tiles_x <= 0) return p;
+    const int tile = p >> 6, in = p & 63;
+    const int ty = tile / pp.tiles_x, tx = tile - ty * pp.tiles_x;
+    return (ty * 8 + (in >> 3)) * pp.W + tx * 8 + (in & 7);
+}
+__device__ __forceinline__ int position_of(const PassParams &pp, int pixel) {
+    if (pp.tiles_x <= 0) return pixel;
+    const int row = pixel / pp.W, col = pixel - row * pp.W;
+    return ((row >> 3) * pp.tiles_x + (col >> 3)) * 64 + (row & 7) * 8 + (col & 7);
+}
 
 struct WfBuffers {
     // Camera-path state of the paths ALIVE at a vertex, dense (index = rank in the vertex's queue) and ping-ponged by
@@ -147,7 +162,7 @@ __global__ __launch_bounds__(kBlock) void k_raygen(DScene sc, PassParams pp, WfB
     const bool live = pid < n;
     f3 dir = mk3(0.f, 0.f, 1.f);
     if (live) {
-        const int slot = pid / pp.npix, pixel = pid - slot * pp.npix;
+        const int slot = pid / pp.npix, pixel = pixel_of(pp, pid - slot * pp.npix);
         const int sample = pp.sample0 + slot * pp.sample_stride;
         const int row = pixel / pp.W, col = pixel - row * pp.W;
         Rng rng;
@@ -176,7 +191,7 @@ __global__ __launch_bounds__(kBlock) void k_lightgen(DScene sc, PassParams pp, W
     const bool live = pid < n;
     f3 lo = mk3(0.f, 0.f, 0.f), ld = mk3(0.f, 0.f, 1.f);
     if (live) {
-        const int slot = pid / pp.npix, pixel = pid - slot * pp.npix;
+        const int slot = pid / pp.npix, pixel = pixel_of(pp, pid - slot * pp.npix);
         Rng rng;
         rng.init(pp.seed, (uint32_t)pixel, (uint32_t)(pp.sample0 + slot * pp.sample_stride), b.path_rng[pid]);
         int li = (int)(rng.u() * ((float)sc.n_lights));  // kernel.cu:178
@@ -228,7 +243,7 @@ __global__ __launch_bounds__(kBlock) void k_light_shade(DScene sc, PassParams pp
                     pdf = st.w;  // light_pdf[i] = light_pdf[i-1] * pdf_brdf, carried from vertex i-1
                 }
                 if (i < pp.Dl - 1) {
-                    const int slot = pid / pp.npix, pixel = pid - slot * pp.npix;
+                    const int slot = pid / pp.npix, pixel = pixel_of(pp, pid - slot * pp.npix);
                     Rng rng;
                     rng.init(pp.seed, (uint32_t)pixel, (uint32_t)(pp.sample0 + slot * pp.sample_stride), b.path_rng[pid]);
                     const float pd = avg3(s.kd), pm = avg3(s.ks);
@@ -351,7 +366,7 @@ __global__ __launch_bounds__(kBlock) void k_shade(DScene sc, PassParams pp, WfBu
                     mask |= 1u << (1 + jj);
                 }
                 if (i + 1 < pp.Dc) {  // next vertex (Q16); nothing downstream reads it after the last vertex
-                    const int slot = pid / pp.npix, pixel = pid - slot * pp.npix;
+                    const int slot = pid / pp.npix, pixel = pixel_of(pp, pid - slot * pp.npix);
                     Rng rng;
                     rng.init(pp.seed, (uint32_t)pixel, (uint32_t)(pp.sample0 + slot * pp.sample_stride),
                              by_id ? b.path_rng[pid] : as_u32(o4.w));
@@ -437,10 +452,11 @@ __global__ __launch_bounds__(kBlock) void k_resolve(PassParams pp, WfBuffers b, 
 __global__ __launch_bounds__(kBlock) void k_accumulate(PassParams pp, WfBuffers b, float *accum) {
     const int pixel = blockIdx.x * kBlock + threadIdx.x;
     if (pixel >= pp.npix) return;
+    const int pos = position_of(pp, pixel);
     float ax = accum[3 * (size_t)pixel], ay = accum[3 * (size_t)pixel + 1], az = accum[3 * (size_t)pixel + 2];
     const float ns = (float)pp.spp;
     for (int s = 0; s < pp.n_slots; s++) {
-        const f4 r = b.path_rad[(size_t)s * pp.npix + pixel];
+        const f4 r = b.path_rad[(size_t)s * pp.npix + pos];
         ax = ax + r.x / ns;
         ay = ay + r.y / ns;
         az = az + r.z / ns;
@@ -575,6 +591,7 @@ int wavefront_render(const HostScene &hs, DeviceCtx &dc, const mipt_render_confi
     PassParams pp;
     pp.W = cfg.width; pp.H = cfg.height; pp.npix = npix; pp.spp = cfg.spp; pp.sample_stride = stride;
     pp.Dc = Dc; pp.Dl = Dl; pp.K = K; pp.use_env = cfg.use_envmap ? 1 : 0; pp.seed = cfg.seed;
+    pp.tiles_x = (cfg.width % 8 == 0 && cfg.height % 8 == 0) ? cfg.width / 8 : 0;
     for (int64_t done = 0; done < n_samples; done += S) {
         pp.n_slots = (int)std::min<int64_t>(S, n_samples - done);
         pp.sample0 = cfg.sample_begin + (int)done * stride;
