@@ -55,8 +55,8 @@ struct EventPool {
 
 // Scheduling knobs of the persistent extend kernel (wave-uniform kernel arguments; MIPT_TUNE="refill,batch,cap").
 struct ExtendTuning {
-    int refill_lanes = 20;      // refill a wave once this many lanes are idle (or all of them)
-    int leaf_batch_lanes = 32;  // scan leaves once this many lanes wait at one (or fewer lanes than this still traverse)
+    int refill_lanes = 32;      // refill a wave once this many lanes are idle (or all of them)
+    int leaf_batch_lanes = 28;  // scan leaves once this many lanes wait at one (or fewer lanes than this still traverse)
     int step_cap = 4;           // node steps per lane per round before lanes re-converge
     // (defaults from the sweeps of scripts/tune.sh on MI355X; the optimum is flat within ~3 % around them)
 };
