@@ -4,8 +4,8 @@
 // visits 1..40 leaves), so the kernel is PERSISTENT: the grid is exactly the number of resident waves, every
 // lane is a small state machine (start mesh -> descend -> leaf -> pop / next mesh -> finish), and a wave
 // refills its idle lanes from a global work counter (ballot + mbcnt rank + one atomic per refill) as soon as
-// enough of them have finished.  The unit of re-convergence is one leaf visit, so a lane never waits for a
-// neighbour's whole ray, only for its current descent / leaf.
+// enough of them have finished.  Lanes re-converge after at most `step_cap` node steps and at every leaf, so a
+// lane never waits for a neighbour's whole ray, only for its current few steps / leaf scan.
 // The traversal stack is an LDS array laid out [slot][lane]: a wave's 64 lanes hit 64 consecutive banks.
 // The ray count is read from device memory (no host round trip between bounces of the wavefront tracer).
 #pragma once
@@ -42,7 +42,9 @@ __device__ __forceinline__ void flush_counters(const TravCounters &tc, unsigned 
     }
 }
 
-// rays: o/d as float4 (w unused), d already normalised by the Ray constructor rule (ray.cuh:10).
+// rays: o/d as float4 (w not read here), d already normalised by the Ray constructor rule (ray.cuh:10).
+// hits: on entry the sphere / plane answer of every ray (quadrics_closest, written by the stage that made the ray),
+//       on exit the closest hit of the scene.
 // queue: optional indirection (slot ids); count_ptr: optional device-side ray count; work: zeroed counter.
 template <bool COUNT>
 __global__ __launch_bounds__(kExtendBlock, 5) void k_extend(DScene sc, const f4 *__restrict__ ray_o,
