@@ -56,6 +56,7 @@ __global__ __launch_bounds__(kExtendBlock, 5) void k_extend(DScene sc, const f4 
     LdsStack stk{stack_mem + threadIdx.x};
     const int n = count_ptr ? *count_ptr : n_fixed;
     const int lane = (int)(threadIdx.x & 63u);
+    const int root0 = sc.n_meshes > 0 ? sc.meshes[0].root : 0;  // wave-uniform: one link less in a fresh ray's load chain
     TravCounters tc = {0u, 0u, 0u, 0u, 0u};
     unsigned int hit_tris = 0;
 #ifdef MIPT_PHASE_STATS
@@ -151,14 +152,14 @@ __global__ __launch_bounds__(kExtendBlock, 5) void k_extend(DScene sc, const f4 
             const int max_tries = sc.n_meshes > 4 ? 4 : 1;
 #pragma unroll 1
             for (int tries = 0; tries < max_tries && m < sc.n_meshes; tries++) {
-                skip_mesh = leaf_culled(sc, sc.meshes[m].root, o, d);
+                skip_mesh = leaf_culled(sc, m == 0 ? root0 : sc.meshes[m].root, o, d);
                 if (!skip_mesh) break;
                 m++;
             }
         }
         if (has_ray && start_mesh && !skip_mesh && m < sc.n_meshes) {
             PSTAT(ps, 3);
-            node = sc.meshes[m].root;
+            node = m == 0 ? root0 : sc.meshes[m].root;
             nd = sc.nodes[node];
             load_slab(sc, node, o, d, cur);
             bool enter;
