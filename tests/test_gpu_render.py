@@ -143,3 +143,27 @@ def test_scene_without_meshes():
     gp, gt, _ = s.trace_closest(ro, rd)
     op, ot, _ = o.trace_closest(ro, rd)
     assert np.array_equal(gp, op) and np.array_equal(gt.view(np.uint32), ot.view(np.uint32))
+
+
+def test_render_argument_errors():
+    from cuda_path_tracer_amd._lib import MiptError
+    desc = G.scene_icosphere_room(2)
+    s = desc.apply(Scene())
+    s.commit(devices=(0,))
+    with pytest.raises(MiptError, match="path depth"):
+        s.render(make_config(16, 16, spp=1, cam_depth=17))
+    with pytest.raises(MiptError, match="spp"):
+        s.render(make_config(16, 16, spp=0))
+    with pytest.raises(MiptError, match="image size"):
+        s.render(make_config(0, 16, spp=1))
+    with pytest.raises(MiptError, match="environment map"):
+        s.render(make_config(16, 16, spp=1, use_envmap=True))
+    nolight = G.scene_icosphere_room(2)
+    nolight.lights.clear()
+    s2 = nolight.apply(Scene())
+    s2.commit(devices=(0,))
+    with pytest.raises(MiptError, match="light"):
+        s2.render(make_config(16, 16, spp=1))
+    # an empty sample range renders nothing and is not an error
+    img, st = s.render(make_config(16, 16, spp=4, sample_begin=2, sample_end=2))
+    assert st["samples"] == 0 and not img.any()
