@@ -19,6 +19,21 @@
 
 namespace mipt {
 
+// Static chunking of an index range over the builder's threads (the pack loops are independent per node / reference).
+template <class F>
+static void parallel_for(int64_t n, int n_threads, F &&body) {
+    const int nt = (int)std::max<int64_t>(1, std::min<int64_t>(n_threads, n / 4096));
+    if (nt <= 1) { body((int64_t)0, n); return; }
+    std::vector<std::thread> th;
+    const int64_t chunk = (n + nt - 1) / nt;
+    for (int k = 0; k < nt; k++) {
+        const int64_t b = k * chunk, e = std::min<int64_t>(n, b + chunk);
+        if (b >= e) break;
+        th.emplace_back([&body, b, e] { body(b, e); });
+    }
+    for (auto &x : th) x.join();
+}
+
 // ------------------------------------------------------------------------------------------ camera
 void camera_set(HostScene &s, const float eye[3], const float lookat[3], const float vup[3], float fov) {
     const f3 e = mk3(eye[0], eye[1], eye[2]), l = mk3(lookat[0], lookat[1], lookat[2]), up = mk3(vup[0], vup[1], vup[2]);
@@ -314,6 +329,7 @@ bool HostScene::pack(int n_threads, std::string &err) {
         err = "scene too large for 30-bit node / 31-bit triangle indices";
         return false;
     }
+    const double t_trees = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     ArenaLayout L;
     size_t off = 0;
     auto section = [&](size_t bytes) { size_t o = off; off = align_up(off + std::max<size_t>(bytes, 16), 256); return o; };
@@ -368,7 +384,8 @@ bool HostScene::pack(int n_threads, std::string &err) {
         // on one of those triangles AND inside the leaf box (mesh.cuh:293-296), so a ray that misses this box -- tested
         // conservatively, see leaf_culled() -- cannot find anything in the leaf and its candidates are skipped.
         float *tight = reinterpret_cast<float *>(A + L.tight) + (size_t)hm.node_base * 8;
-        for (int64_t i = 0; i < hm.n_nodes; i++) {
+        parallel_for(hm.n_nodes, n_threads, [&](int64_t i_begin, int64_t i_end) {
+        for (int64_t i = i_begin; i < i_end; i++) {
             const KdNode k = t.nodes[(size_t)i];
             float *tb = tight + 8 * i;
             const float *nb = t.boxes.data() + 8 * (size_t)i;
@@ -388,6 +405,7 @@ bool HostScene::pack(int n_threads, std::string &err) {
                 tb[2 * a + 1] = std::min(nb[2 * a + 1], hi[a]);
             }
         }
+        });
         // interior nodes: union of the children's cull boxes (children are stored after their parent), so a ray that
         // misses it cannot find anything in the whole subtree and the stacked subtree can be dropped unvisited
         for (int64_t i = hm.n_nodes - 1; i >= 0; i--) {
@@ -403,7 +421,8 @@ bool HostScene::pack(int n_threads, std::string &err) {
         // the same boxes once more, interleaved per sibling pair for the packed cull test of descend_fast()
         if ((hm.node_base & 1) != 0) { err = "internal: odd node base"; return false; }
         float *tpair = reinterpret_cast<float *>(A + L.tight_pairs);
-        for (int64_t i = 0; i < hm.n_nodes; i++) {
+        parallel_for(hm.n_nodes, n_threads, [&](int64_t i_begin, int64_t i_end) {
+        for (int64_t i = i_begin; i < i_end; i++) {
             const KdNode k = t.nodes[(size_t)i];
             if ((k.b >> 30) == 3u) continue;
             const size_t lc = (size_t)(k.b & kIdxMask);
@@ -424,31 +443,37 @@ bool HostScene::pack(int n_threads, std::string &err) {
                 grow(r_empty ? INFINITY : r[2 * a], r_empty ? -INFINITY : r[2 * a + 1], rec[4 * a + 1], rec[4 * a + 3]);
             }
         }
+        });
         int32_t *refs = reinterpret_cast<int32_t *>(A + L.refs) + hm.ref_base;
         for (int64_t i = 0; i < hm.n_refs; i++) refs[i] = t.refs[(size_t)i] + (int32_t)hm.tri_base;
         // leaf-ordered plane records: N = cross(b-a, c-a), dd = -dot(N, a) exactly as Triangle::intersect
         // evaluates them per candidate (mesh.cuh:40-42,52); same fp32 operations, done once here
         float *lp = reinterpret_cast<float *>(A + L.leaf_planes) + (size_t)hm.ref_base * 4;
-        for (int64_t i = 0; i < hm.n_refs; i++) {
+        parallel_for(hm.n_refs, n_threads, [&](int64_t i_begin, int64_t i_end) {
+        for (int64_t i = i_begin; i < i_end; i++) {
             const float *v = hm.pos.data() + (size_t)t.refs[(size_t)i] * 9;
             const f3 a = mk3(v[0], v[1], v[2]), b = mk3(v[3], v[4], v[5]), c = mk3(v[6], v[7], v[8]);
             const f3 N = cross3(b - a, c - a);
             lp[4 * i] = N.x; lp[4 * i + 1] = N.y; lp[4 * i + 2] = N.z;
             lp[4 * i + 3] = -dot3(N, a);
         }
+        });
         float *lv = reinterpret_cast<float *>(A + L.leaf_verts) + (size_t)hm.ref_base * 12;
-        for (int64_t i = 0; i < hm.n_refs; i++) {
+        parallel_for(hm.n_refs, n_threads, [&](int64_t i_begin, int64_t i_end) {
+        for (int64_t i = i_begin; i < i_end; i++) {
             const float *v = hm.pos.data() + (size_t)t.refs[(size_t)i] * 9;
             for (int q = 0; q < 3; q++)
                 for (int c = 0; c < 3; c++) lv[12 * i + 4 * q + c] = v[3 * q + c];
         }
+        });
         // leaf-ordered candidate spheres (no counterpart in the reference; they change no result): a hit the leaf
         // loop accepts lies on the triangle (up to the rounding of the edge tests) and inside the leaf box (up to its
         // 1e-5 slack), i.e. inside both the triangle's smallest enclosing sphere and the sphere around
         // AABB(triangle) ∩ cull box of the leaf.  The smaller of the two, grown by 2^-10 relative + 2^-13 x (largest
         // coordinate, at least 1) absolute, is what leaf_scan() tests the ray against before it evaluates a candidate.
         float *ls = reinterpret_cast<float *>(A + L.leaf_spheres);  // indexed by GLOBAL reference (pairs interleaved)
-        for (int64_t i = 0; i < hm.n_nodes; i++) {
+        parallel_for(hm.n_nodes, n_threads, [&](int64_t i_begin, int64_t i_end) {
+        for (int64_t i = i_begin; i < i_end; i++) {
             const KdNode k = t.nodes[(size_t)i];
             if ((k.b >> 30) != 3u) continue;
             const float *tb = tight + 8 * i;
@@ -528,14 +553,17 @@ bool HostScene::pack(int n_threads, std::string &err) {
                 rec[6] = R2;
             }
         }
+        });
         float *tp = reinterpret_cast<float *>(A + L.tri_pos) + (size_t)hm.tri_base * 12;
         float *tn = reinterpret_cast<float *>(A + L.tri_nrm) + (size_t)hm.tri_base * 12;
-        for (int64_t i = 0; i < hm.n_tris * 3; i++) {
+        parallel_for(hm.n_tris * 3, n_threads, [&](int64_t i_begin, int64_t i_end) {
+        for (int64_t i = i_begin; i < i_end; i++) {
             for (int k = 0; k < 3; k++) {
                 tp[4 * i + k] = hm.pos[(size_t)(3 * i + k)];
                 tn[4 * i + k] = hm.nrm[(size_t)(3 * i + k)];
             }
         }
+        });
         DMesh dm;
         dm.root = (int32_t)hm.node_base;
         dm.tri_base = (int32_t)hm.tri_base;
@@ -572,6 +600,7 @@ bool HostScene::pack(int n_threads, std::string &err) {
     layout = L;
     packed = true;
     build_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    if (getenv("MIPT_TIMING")) fprintf(stderr, "[mipt] kd trees %.3f s, pack %.3f s (%d threads)\n", t_trees, build_seconds - t_trees, n_threads);
     return true;
 }
 
