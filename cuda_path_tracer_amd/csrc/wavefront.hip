@@ -525,10 +525,10 @@ int wavefront_render(const HostScene &hs, DeviceCtx &dc, const mipt_render_confi
     WF_TRY(hipSetDevice(dc.device));
     if (n_samples == 0 || Dc == 0) return 0;
     int S = cfg.samples_per_pass;
-    // auto: ~64 M paths per pass (11 GB of path state for simple PT, 4 % of the HBM).  The persistent extend kernel holds
-    // ~330 k rays at a time and every launch pays a ramp-up and a tail in which its waves run dry one by one; at 1080p
-    // that costs 122 -> 285 -> 349 -> 384 -> 402 -> 412 Msamples/s for 1, 2, 4, 8, 16, 32 samples of every pixel per pass
-    if (S <= 0) S = (int)std::max<int64_t>(1, ((int64_t)1 << 26) / npix);
+    // auto: ~128 M paths per pass (28 GB of path state for simple PT, 10 % of the HBM).  The persistent extend kernel
+    // holds ~330 k rays at a time and every launch pays a ramp-up and a tail in which its waves run dry one by one; at
+    // 1080p 16 / 32 / 64 / 128 samples of every pixel per pass give 476 / 490 / 497 / 500 Msamples/s (1 per pass: 122)
+    if (S <= 0) S = (int)std::max<int64_t>(1, ((int64_t)1 << 27) / npix);
     S = (int)std::min<int64_t>(std::min<int64_t>(S, n_samples), std::max<int64_t>(1, ((int64_t)1 << 28) / ((int64_t)npix * K)));
     const size_t P = (size_t)S * npix;
 
