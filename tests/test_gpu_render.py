@@ -167,3 +167,23 @@ def test_render_argument_errors():
     # an empty sample range renders nothing and is not an error
     img, st = s.render(make_config(16, 16, spp=4, sample_begin=2, sample_end=2))
     assert st["samples"] == 0 and not img.any()
+
+
+def test_two_device_slots_in_one_process():
+    # mipt_render over several committed device slots (one host thread and stream per slot, samples s mod G, host sum).
+    # With one GPU in the box both slots live on device 0, which still runs the whole multi-slot code path.
+    desc = G.scene_icosphere_room(3)
+    two = desc.apply(Scene())
+    two.commit(devices=(0, 0))
+    one = desc.apply(Scene())
+    one.commit(devices=(0,))
+    cfg = make_config(64, 48, spp=6, cam_depth=5)
+    img2, st2 = two.render(cfg)
+    parts = []
+    for g in range(2):
+        c = make_config(64, 48, spp=6, cam_depth=5, sample_begin=g, sample_end=6, sample_stride=2)
+        parts.append(one.render(c)[0])
+    assert np.array_equal(img2.view(np.uint32), (parts[0] + parts[1]).view(np.uint32))
+    full, st1 = one.render(cfg)
+    assert np.allclose(img2, full, rtol=2e-6, atol=1e-7)  # same samples, different fp32 summation order
+    assert st2["samples"] == st1["samples"] == 64 * 48 * 6 and st2["rays_total"] == st1["rays_total"]
