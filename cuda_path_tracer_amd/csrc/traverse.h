@@ -540,6 +540,16 @@ PT_HD bool misses_every_mesh(const DScene &sc, f3 o, f3 d) {
     return true;
 }
 
+// Visibility by position compare (Q10): did the closest hit `t` of the shadow / connection ray (o, d) land on the point
+// it was aimed at?  target.w == 0: ray cast from the light at a surface point (kernel.cu:249); else: connection ray
+// from a camera vertex to a light vertex (kernel.cu:268).  One definition for every stage that resolves a shadow ray.
+PT_HD bool shadow_visible(f3 o, f3 d, float t, f4 target) {
+    const f3 P = o + d * t;
+    const float dist = len3(P - mk3(target.x, target.y, target.z));
+    if (target.w == 0.0f) return (t > 0.0f) && (dist < kEps);
+    return !((t < 0.0f) || (dist > kEps));
+}
+
 // Scene::firstIntersect (kernel.cu:145-160): meshes, spheres, planes; strict '<' keeps the earlier object.
 // prim: -1 miss; [0,total_tris) triangle; then spheres; then planes.
 template <class Stack, bool COUNT>

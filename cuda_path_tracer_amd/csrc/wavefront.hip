@@ -338,7 +338,7 @@ __global__ __launch_bounds__(kBlock) void k_shade(DScene sc, PassParams pp, WfBu
                         b.sh_o[sbase] = mk4(lp, 0.f);
                         b.sh_d[sbase] = mk4(norm3(ld), 0.f);
                         b.sh_target[sbase] = mk4(s.pos, 0.f);
-                        b.sh_contrib[sbase] = mk4(contrib, 0.f);
+                        b.sh_contrib[sbase] = mk4(contrib, as_f32((uint32_t)pid));
                         mask |= 1u;
                     }
                 }
@@ -362,7 +362,7 @@ __global__ __launch_bounds__(kBlock) void k_shade(DScene sc, PassParams pp, WfBu
                     b.sh_o[si] = mk4(s.pos + s.nrm * kEps, 0.f);
                     b.sh_d[si] = mk4(norm3(dir), 0.f);
                     b.sh_target[si] = mk4(xyz(lp4), 1.f);
-                    b.sh_contrib[si] = mk4(contrib, 0.f);
+                    b.sh_contrib[si] = mk4(contrib, as_f32((uint32_t)pid));
                     mask |= 1u << (1 + jj);
                 }
                 if (i + 1 < pp.Dc) {  // next vertex (Q16); nothing downstream reads it after the last vertex
@@ -418,33 +418,43 @@ __global__ __launch_bounds__(kBlock) void k_shade(DScene sc, PassParams pp, WfBu
     if ((threadIdx.x & 63u) == 0 && n_trivial > 0) atomicAdd(&b.counts[kCntPad * (kCntShadowTriv + i)], n_trivial);
 }
 
-// visibility + accumulation for vertex i (kernel.cu:249-256, 268-279)
-__global__ __launch_bounds__(kBlock) void k_resolve(PassParams pp, WfBuffers b, int i) {
+// visibility + accumulation for vertex i (kernel.cu:249-256, 268-279).  HBM-bound: it reads as little as it can -- the
+// ray of a direct connection is recomputed from its target (same operations as k_shade: origin = lights[0], direction
+// = normalised twice, kernel.cu:245-248 + ray.cuh:10), the path id rides in contrib.w, and the radiance is only
+// touched by paths with a visible contribution: 28 B per path + 48 B per visible one instead of 124 B per path.
+__global__ __launch_bounds__(kBlock) void k_resolve(DScene sc, PassParams pp, WfBuffers b, int i) {
     const int n = b.counts[kCntPad * (kCntCam + i)];
-    const int par = i & 1;
     const bool by_id = (i == 0) && (pp.Dl != 0);
+    const f3 lp = xyz(sc.lights[0]);
     for (int idx = blockIdx.x * kBlock + threadIdx.x; idx < n; idx += gridDim.x * kBlock) {
         const int j = by_id ? b.q_cam0[idx] : idx;
         const uint32_t mask = b.sh_mask[j];
         if (mask == 0u) continue;
-        const int pid = (int)as_u32(b.st_d[par][j].w);
-        f4 r = b.path_rad[pid];
+        f4 r = f4{0.f, 0.f, 0.f, 0.f};
+        int pid = -1;
         for (int k = 0; k < pp.K; k++) {
             if (!((mask >> k) & 1u)) continue;
             const size_t si = (size_t)j * pp.K + k;
             const HitRec h = b.sh_hit[si];
             const f4 tg = b.sh_target[si];
-            const f3 P = xyz(b.sh_o[si]) + xyz(b.sh_d[si]) * h.t;
-            const float dist = len3(P - xyz(tg));
-            bool vis;
-            if (tg.w == 0.0f) vis = (h.t > 0.0f) && (dist < kEps);   // kernel.cu:249
-            else vis = !((h.t < 0.0f) || (dist > kEps));              // kernel.cu:268
-            if (vis) {
+            f3 o, d;
+            if (k == 0) {
+                o = lp;
+                d = norm3(norm3(xyz(tg) - lp));
+            } else {
+                o = xyz(b.sh_o[si]);
+                d = xyz(b.sh_d[si]);
+            }
+            if (shadow_visible(o, d, h.t, tg)) {
                 const f4 c = b.sh_contrib[si];
+                if (pid < 0) {
+                    pid = (int)as_u32(c.w);
+                    r = b.path_rad[pid];
+                }
                 r.x = r.x + c.x; r.y = r.y + c.y; r.z = r.z + c.z;
             }
         }
-        b.path_rad[pid] = r;
+        if (pid >= 0) b.path_rad[pid] = r;
     }
 }
 
@@ -611,7 +621,7 @@ int wavefront_render(const HostScene &hs, DeviceCtx &dc, const mipt_render_confi
             extend(b.st_o[i & 1], b.st_d[i & 1], b.q_ext_cam, &b.counts[kCntPad * (kCntExtCam + i)], b.st_hit[i & 1], np);
             hipLaunchKernelGGL(k_shade, dim3(path_grid), dim3(kBlock), 0, sm, dc.view, pp, b, i);
             extend(b.sh_o, b.sh_d, b.q_shadow, &b.counts[kCntPad * (kCntShadow + i)], b.sh_hit, np * K);
-            hipLaunchKernelGGL(k_resolve, dim3(path_grid), dim3(kBlock), 0, sm, pp, b, i);
+            hipLaunchKernelGGL(k_resolve, dim3(path_grid), dim3(kBlock), 0, sm, dc.view, pp, b, i);
             // the shadow queue is refilled from slot 0 by the next vertex: its count lives in its own slot
         }
         hipLaunchKernelGGL(k_accumulate, dim3((unsigned)((npix + kBlock - 1) / kBlock)), dim3(kBlock), 0, sm, pp, b, d_accum);
