@@ -63,10 +63,14 @@ PT_HD uint32_t as_u32(float f) {
 PT_HD float fmin_raw(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 PT_HD float fmax_raw(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 PT_HD float fmin3_raw(float a, float b, float c) { float r; asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+// v_rcp_f32, 1 ulp.  (__frcp_rn and 1.0f / x are a 13-instruction IEEE division under
+// -fhip-fp32-correctly-rounded-divide-sqrt; only the conservative cull tests may use this one.)
+PT_HD float rcp_approx(float x) { return __builtin_amdgcn_rcpf(x); }
 #else
 PT_HD float fmin_raw(float a, float b) { return a < b ? a : b; }
 PT_HD float fmax_raw(float a, float b) { return a > b ? a : b; }
 PT_HD float fmin3_raw(float a, float b, float c) { return fmin_raw(fmin_raw(a, b), c); }
+PT_HD float rcp_approx(float x) { return 1.0f / x; }
 #endif
 
 // Box::isVertexInBox (mesh.cuh:131-139): min-X has no epsilon, every other bound has +eps slack (Q5)
@@ -241,7 +245,7 @@ PT_HD void pair_culled(f4 bx, f4 by, f4 bz, f3 o, f3 d, bool &cull_l, bool &cull
             out_l |= (oo[k] < l.x) | (oo[k] > h.x);
             out_r |= (oo[k] < l.y) | (oo[k] > h.y);
         } else {
-            const float inv = __frcp_rn(dd[k]);  // a 1-ulp reciprocal is plenty: the test is conservative by 2^-12
+            const float inv = rcp_approx(dd[k]);  // a 1-ulp reciprocal is plenty: the test is conservative by 2^-12
             const v2f t0 = (l - oo[k]) * inv, t1 = (h - oo[k]) * inv;
             tn_l = fmax_raw(tn_l, fmin_raw(t0.x, t1.x));
             tf_l = fmin_raw(tf_l, fmax_raw(t0.x, t1.x));
@@ -367,7 +371,7 @@ PT_HD bool box_culled(f4 b0, f4 b1, f3 o, f3 d) {
         if (fabsf(dd[k]) < 1e-30f) {
             out |= (oo[k] < l) | (oo[k] > h);
         } else {
-            const float inv = __frcp_rn(dd[k]);  // a 1-ulp reciprocal is plenty: the test is conservative by 2^-12
+            const float inv = rcp_approx(dd[k]);  // a 1-ulp reciprocal is plenty: the test is conservative by 2^-12
             const float t0 = (l - oo[k]) * inv, t1 = (h - oo[k]) * inv;
             tn = fmaxf(tn, fminf(t0, t1));
             tf = fminf(tf, fmaxf(t0, t1));
