@@ -150,9 +150,11 @@ __global__ __launch_bounds__(kExtendBlock, 5) void k_extend(DScene sc, const f4 
             // (bounded: lanes in other states wait meanwhile; with few meshes one try per round measured faster --
             //  default scene, 3 meshes: 523 vs 433 Msamples/s bidirectional; 8 meshes: 49 vs 54 the other way)
             const int max_tries = sc.n_meshes > 4 ? 4 : 1;
+            const float inf = __builtin_inff();
+            const float t_max = fmin_raw(best > 0.0f ? best : inf, q_t > 0.0f ? q_t : inf);  // closest answer so far
 #pragma unroll 1
             for (int tries = 0; tries < max_tries && m < sc.n_meshes; tries++) {
-                skip_mesh = leaf_culled(sc, m == 0 ? root0 : sc.meshes[m].root, o, d);
+                skip_mesh = mesh_skippable(sc, m == 0 ? root0 : sc.meshes[m].root, o, d, t_max);
                 if (!skip_mesh) break;
                 m++;
             }

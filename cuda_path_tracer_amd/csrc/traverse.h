@@ -383,6 +383,34 @@ PT_HD bool box_culled(f4 b0, f4 b1, f3 o, f3 d) {
 PT_HD bool leaf_culled(const DScene &sc, int node, f3 o, f3 d) {
     return box_culled(sc.tight[2 * (size_t)node], sc.tight[2 * (size_t)node + 1], o, d);
 }
+// Whole-mesh skip with a distance bound (no counterpart in the reference; it changes no result): besides missing the
+// root cull box, a ray also cannot be given a USED hit by a mesh whose root cull box it enters strictly beyond t_max =
+// the closest answer so far (earlier meshes, spheres, planes) -- every accepted hit of that mesh lies inside the box,
+// hence at t > t_max, and Scene::firstIntersect (kernel.cu:147-158) keeps the earlier object on ties.  Only a WHOLE
+// mesh may be dropped this way: inside a mesh the first leaf with an accepted hit ends the search (Q8), so pruning
+// subtrees by distance could expose a later, nearer leaf the reference never reaches.
+PT_HD bool mesh_skippable(const DScene &sc, int root, f3 o, f3 d, float t_max) {
+    const f4 b0 = sc.tight[2 * (size_t)root], b1 = sc.tight[2 * (size_t)root + 1];
+    const float lo[3] = {b0.x, b0.z, b1.x}, hi[3] = {b0.y, b0.w, b1.y};
+    const float oo[3] = {o.x, o.y, o.z}, dd[3] = {d.x, d.y, d.z};
+    float tn = 0.0f, tf = __builtin_inff();
+    bool out = false;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const float mg = 2.44140625e-4f * fmaxf(fmaxf(fabsf(lo[k]), fabsf(hi[k])), fmaxf(fabsf(oo[k]), 1.0f));
+        const float l = lo[k] - mg, h = hi[k] + mg;
+        if (fabsf(dd[k]) < 1e-30f) {
+            out |= (oo[k] < l) | (oo[k] > h);
+        } else {
+            const float inv = rcp_approx(dd[k]);
+            const float t0 = (l - oo[k]) * inv, t1 = (h - oo[k]) * inv;
+            tn = fmaxf(tn, fminf(t0, t1));
+            tf = fminf(tf, fmaxf(t0, t1));
+        }
+    }
+    const bool beyond = tn - 2.44140625e-4f * (tn + 1.0f) > t_max;  // tn >= 0; same relative widening as the interval test
+    return out | beyond | (tn > tf + 2.44140625e-4f * (fabsf(tf) + 1.0f)) | !(lo[0] <= hi[0]);
+}
 
 PT_HD void leaf_scan(const DScene &sc, int first, int count, f3 o, f3 d, const SlabBox &cur, float &bt, int &bi PSTAT_ARG);
 
