@@ -80,7 +80,8 @@ __global__ __launch_bounds__(kExtendBlock, 5) void k_extend(DScene sc, const f4 
     // keeps the earlier mesh on ties), else continue with the stacked far child, else the mesh is exhausted
     auto after_leaf = [&](float bt, int bi) {
         if (bt > 0.0f) {
-            if (best < 0.0f || bt < best) { best = bt; prim = bi; }
+            // (equal hits: the lower triangle id is the earlier mesh -- the production kernel opens meshes out of order)
+            if (best < 0.0f || bt < best || (bt == best && bi < prim)) { best = bt; prim = bi; }
             m++;
             start_mesh = true;
         } else if (sp == 0 || sp > kStackDepth) {  // (sp > kStackDepth: unreachable for trees of kd_build.cpp)
@@ -146,6 +147,15 @@ __global__ __launch_bounds__(kExtendBlock, 5) void k_extend(DScene sc, const f4 
         // ---- open the next mesh: root box test (mesh.cuh:254) -------------------------------------------------
         // a mesh whose root cull box the ray misses cannot be hit: skipped before any exact slab arithmetic
         bool skip_mesh = false;
+        // position m -> root of the m-th mesh along the ray's dominant axis, near to far (sc.mesh_order)
+        auto root_at = [&](int pos) -> int {
+            if (COUNT) return sc.meshes[pos].root;  // the reference's order
+            if (sc.n_meshes == 1) return root0;
+            const float ax = fabsf(d.x), ay = fabsf(d.y), az = fabsf(d.z);
+            const int a = (ax >= ay && ax >= az) ? 0 : (ay >= az ? 1 : 2);
+            const float da = a == 0 ? d.x : (a == 1 ? d.y : d.z);
+            return sc.mesh_order[a * sc.n_meshes + (da < 0.0f ? sc.n_meshes - 1 - pos : pos)];
+        };
         if (!COUNT && has_ray && start_mesh) {
             // (bounded: lanes in other states wait meanwhile; with few meshes one try per round measured faster --
             //  default scene, 3 meshes: 523 vs 433 Msamples/s bidirectional; 8 meshes: 49 vs 54 the other way)
@@ -154,14 +164,14 @@ __global__ __launch_bounds__(kExtendBlock, 5) void k_extend(DScene sc, const f4 
             const float t_max = fmin_raw(best > 0.0f ? best : inf, q_t > 0.0f ? q_t : inf);  // closest answer so far
 #pragma unroll 1
             for (int tries = 0; tries < max_tries && m < sc.n_meshes; tries++) {
-                skip_mesh = mesh_skippable(sc, m == 0 ? root0 : sc.meshes[m].root, o, d, t_max);
+                skip_mesh = mesh_skippable(sc, root_at(m), o, d, t_max);
                 if (!skip_mesh) break;
                 m++;
             }
         }
         if (has_ray && start_mesh && !skip_mesh && m < sc.n_meshes) {
             PSTAT(ps, 3);
-            node = m == 0 ? root0 : sc.meshes[m].root;
+            node = root_at(m);
             nd = sc.nodes[node];
             load_slab(sc, node, o, d, cur);
             bool enter;

@@ -344,6 +344,7 @@ bool HostScene::pack(int n_threads, std::string &err) {
     L.tri_pos = section((size_t)total_tris * 48);
     L.tri_nrm = section((size_t)total_tris * 48);
     L.meshes = section(meshes.size() * sizeof(DMesh));
+    L.mesh_order = section(3 * meshes.size() * 4);
     L.spheres = section(spheres.size() * 32);
     L.planes = section(planes.size() * 32);
     L.lights = section(lights.size() * 32);
@@ -571,6 +572,22 @@ bool HostScene::pack(int n_threads, std::string &err) {
         dm.material = hm.material;
         reinterpret_cast<DMesh *>(A + L.meshes)[m] = dm;
     }
+    {  // evaluation order of the meshes for the extend kernel (any order gives Scene::firstIntersect's answer as long
+       // as equal hits go to the lower triangle id, i.e. the earlier mesh, kernel.cu:147-150)
+        int32_t *mo = reinterpret_cast<int32_t *>(A + L.mesh_order);
+        const float *tight = reinterpret_cast<const float *>(A + L.tight);
+        std::vector<int> idx(meshes.size());
+        for (int ax = 0; ax < 3; ax++) {
+            for (size_t m = 0; m < meshes.size(); m++) idx[m] = (int)m;
+            auto centre = [&](int m) {
+                const float *b = tight + 8 * (size_t)meshes[(size_t)m].node_base;
+                const float lo = b[2 * ax], hi = b[2 * ax + 1];
+                return (lo <= hi) ? 0.5f * (lo + hi) : 0.0f;  // empty mesh: anywhere
+            };
+            std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) { return centre(a) < centre(b); });
+            for (size_t m = 0; m < meshes.size(); m++) mo[(size_t)ax * meshes.size() + m] = (int32_t)meshes[(size_t)idx[m]].node_base;
+        }
+    }
     float *sp = reinterpret_cast<float *>(A + L.spheres);
     for (size_t i = 0; i < spheres.size(); i++) {
         const HostSphere &s = spheres[i];
@@ -619,6 +636,7 @@ DScene HostScene::view(const void *base_v) const {
     d.tri_pos = reinterpret_cast<const f4 *>(base + layout.tri_pos);
     d.tri_nrm = reinterpret_cast<const f4 *>(base + layout.tri_nrm);
     d.meshes = reinterpret_cast<const DMesh *>(base + layout.meshes);
+    d.mesh_order = reinterpret_cast<const int32_t *>(base + layout.mesh_order);
     d.spheres = reinterpret_cast<const f4 *>(base + layout.spheres);
     d.planes = reinterpret_cast<const f4 *>(base + layout.planes);
     d.lights = reinterpret_cast<const f4 *>(base + layout.lights);

@@ -76,6 +76,8 @@ struct DScene {
     const f4 *tri_pos;
     const f4 *tri_nrm;
     const DMesh *meshes;
+    const int32_t *mesh_order;  // [3][n_meshes] ROOT node of the meshes sorted by the centre of their root cull box along
+                                // x, y, z: the extend kernel opens meshes near-to-far along the ray's dominant axis
     const f4 *spheres;    // 2 per sphere: (center, radius) (mat bits, -, -, -)
     const f4 *planes;     // 2 per plane:  (point, mat bits) (normal, -)
     const f4 *lights;     // 2 per light:  (location, -) (power, -)

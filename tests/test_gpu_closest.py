@@ -88,6 +88,31 @@ def test_overlapping_meshes():
     _check(G.scene_multi_sphere(4), 16384, lattice=8)
 
 
+def _scene_coincident_meshes():
+    """Three meshes, two of them the SAME triangles at the same place (every hit ties exactly) listed around a shifted
+    one: Scene::firstIntersect keeps the earlier mesh on ties (kernel.cu:147-150), whatever order they are opened in."""
+    d = G.scene_icosphere_room(3)
+    kind, pos, nrm, mat = d.meshes[0]
+    d.meshes.append((kind, pos + np.array([1.5, 0.25, 0.5], np.float32), nrm, mat))
+    d.meshes.append((kind, pos.copy(), nrm, mat))
+    return d
+
+
+def test_coincident_meshes_tie_goes_to_the_earlier_mesh():
+    desc = _scene_coincident_meshes()
+    s, o = _check(desc, 16384, lattice=8)
+    ro, rd = _rays(desc, 8192)
+    rd2 = -rd  # the production kernel opens meshes along the dominant axis: exercise both directions
+    ro2 = ro + 12.0 * rd / np.linalg.norm(rd, axis=1, keepdims=True)
+    ro, rd = np.concatenate([ro, ro2]), np.concatenate([rd, rd2])
+    op, ot, _ = o.trace_closest(ro, rd)
+    gp, gt, _ = s.trace_closest(ro, rd)
+    _same(gp, gt, op, ot, "production kernel, both directions")
+    n0 = pos_tris = desc.meshes[0][1].shape[0]
+    assert not np.any((gp >= 2 * n0) & (gp < 3 * n0)), "the copy listed last never wins a tie against mesh 0"
+    assert np.any((gp >= 0) & (gp < n0)) and np.any((gp >= n0) & (gp < 2 * n0))
+
+
 def test_far_origins():
     """Origins 10^2 .. 10^6 scene sizes away, aimed at the mesh: the reference's own P = o + d t is then coarse (ulp of
     |o|), and the conservative tests of the production kernel must still never cull what the reference accepts."""

@@ -187,3 +187,16 @@ def test_two_device_slots_in_one_process():
     full, st1 = one.render(cfg)
     assert np.allclose(img2, full, rtol=2e-6, atol=1e-7)  # same samples, different fp32 summation order
     assert st2["samples"] == st1["samples"] == 64 * 48 * 6 and st2["rays_total"] == st1["rays_total"]
+
+
+def test_coincident_meshes_render_bit_exact():
+    """Exactly tying hits on two identical meshes + a third overlapping one: simple and bidirectional images."""
+    d = G.scene_icosphere_room(3)
+    kind, pos, nrm, mat = d.meshes[0]
+    d.meshes.append((kind, pos + np.array([1.5, 0.25, 0.5], np.float32), nrm, mat))
+    d.meshes.append((kind, pos.copy(), nrm, mat))
+    s, o = _pair(d)
+    for cfg in (make_config(64, 48, spp=3, cam_depth=5, light_depth=0), make_config(48, 40, spp=2, cam_depth=3, light_depth=3)):
+        img, _ = s.render(cfg)
+        ref, _ = o.render(cfg)
+        assert np.array_equal(img.view(np.uint32), ref.view(np.uint32))
