@@ -67,7 +67,13 @@ __global__ __launch_bounds__(kExtendBlock, 5) void k_extend(DScene sc, const f4 
     bool start_mesh = false;  // lane must open mesh `m`, or store its result when m == n_meshes
     bool pending = false;     // lane sits at an un-culled leaf (`nd`) waiting for a batched scan
     bool need_pop = false;    // lane must continue with the node on top of its stack
-    int slot = 0, m = 0, node = 0, sp = 0;
+    // two flags ride in the top bits of `slot` (< 2^30, touched only at fetch and store) to stay inside 96 VGPRs:
+    //   kTaintBit   this mesh's search dropped a subtree by distance (see descend_fast)
+    //   kNoPruneBit ... and then found a hit that counts: the mesh is being repeated without distance pruning
+    constexpr uint32_t kTaintBit = 1u << 31, kNoPruneBit = 1u << 30, kSlotMask = (1u << 30) - 1u;
+    const bool prune_meshes = !COUNT && sc.n_meshes > 1;  // wave-uniform
+    uint32_t slot = 0u;
+    int m = 0, node = 0, sp = 0;
     int prim = -1, q_prim = -1;      // best mesh triangle / best sphere-or-plane
     float best = -1.0f, q_t = -1.0f;
     KdNode nd = {0u, kLeafTag};      // the 8 bytes of `node`
@@ -78,15 +84,22 @@ __global__ __launch_bounds__(kExtendBlock, 5) void k_extend(DScene sc, const f4 
 
     // what follows a leaf visit: bt > 0 = accepted hit at triangle bi (mesh.cuh:300 ends this mesh; kernel.cu:149
     // keeps the earlier mesh on ties), else continue with the stacked far child, else the mesh is exhausted
+    const float inf = __builtin_inff();
+    auto closest_so_far = [&]() { return fmin_raw(best > 0.0f ? best : inf, q_t > 0.0f ? q_t : inf); };
     auto after_leaf = [&](float bt, int bi) {
-        if (bt > 0.0f) {
+        if (prune_meshes && bt > 0.0f && (slot & kTaintBit) != 0u && bt <= closest_so_far()) {
+            slot |= kNoPruneBit;  // the hit would be used, but the reference may have stopped in a subtree that was dropped
+            start_mesh = true;
+        } else if (bt > 0.0f) {
             // (equal hits: the lower triangle id is the earlier mesh -- the production kernel opens meshes out of order)
             if (best < 0.0f || bt < best || (bt == best && bi < prim)) { best = bt; prim = bi; }
             m++;
             start_mesh = true;
+            slot &= ~kNoPruneBit;
         } else if (sp == 0 || sp > kStackDepth) {  // (sp > kStackDepth: unreachable for trees of kd_build.cpp)
             m++;
             start_mesh = true;
+            slot &= ~kNoPruneBit;
         } else {
             need_pop = true;
         }
@@ -102,7 +115,7 @@ __global__ __launch_bounds__(kExtendBlock, 5) void k_extend(DScene sc, const f4 
             HitRec h;
             h.t = mesh_wins ? best : q_t;
             h.prim = mesh_wins ? prim : q_prim;
-            hits[slot] = h;
+            hits[slot & kSlotMask] = h;
             if (COUNT) hit_tris += mesh_wins ? 1u : 0u;
             has_ray = false;
             start_mesh = false;
@@ -120,7 +133,7 @@ __global__ __launch_bounds__(kExtendBlock, 5) void k_extend(DScene sc, const f4 
                                                                 __builtin_amdgcn_mbcnt_lo((unsigned int)idle, 0u));
                 if (!has_ray && base + rank < n) {
                     PSTAT(ps, 2);
-                    slot = queue ? queue[base + rank] : base + rank;
+                    slot = (uint32_t)(queue ? queue[base + rank] : base + rank);
                     const f4 o4 = ray_o[slot], d4 = ray_d[slot];
                     o = mk3(o4.x, o4.y, o4.z);
                     d = mk3(d4.x, d4.y, d4.z);
@@ -160,8 +173,7 @@ __global__ __launch_bounds__(kExtendBlock, 5) void k_extend(DScene sc, const f4 
             // (bounded: lanes in other states wait meanwhile; with few meshes one try per round measured faster --
             //  default scene, 3 meshes: 523 vs 433 Msamples/s bidirectional; 8 meshes: 49 vs 54 the other way)
             const int max_tries = sc.n_meshes > 4 ? 4 : 1;
-            const float inf = __builtin_inff();
-            const float t_max = fmin_raw(best > 0.0f ? best : inf, q_t > 0.0f ? q_t : inf);  // closest answer so far
+            const float t_max = closest_so_far();
 #pragma unroll 1
             for (int tries = 0; tries < max_tries && m < sc.n_meshes; tries++) {
                 skip_mesh = mesh_skippable(sc, root_at(m), o, d, t_max);
@@ -184,6 +196,7 @@ __global__ __launch_bounds__(kExtendBlock, 5) void k_extend(DScene sc, const f4 
             if (enter) {
                 sp = 0;
                 start_mesh = false;
+                slot &= ~kTaintBit;
                 if (COUNT) { tc.pops++; tc.nodes++; }
                 else if ((nd.b >> 30) == 3u) pending = true;  // single-leaf mesh
             } else {
@@ -243,7 +256,8 @@ __global__ __launch_bounds__(kExtendBlock, 5) void k_extend(DScene sc, const f4 
                 after_leaf(-1.0f, -1);
             }
         } else {
-            const bool dead_end = descend_fast<LdsStack>(sc, o, d, cur, node, nd, sp, stk, tune.step_cap PSTAT_PASS);
+            const float t_prune = (prune_meshes && (slot & kNoPruneBit) == 0u) ? closest_so_far() : inf;
+            const bool dead_end = descend_fast<LdsStack>(sc, o, d, cur, node, nd, sp, stk, tune.step_cap, prune_meshes, t_prune, slot, kTaintBit PSTAT_PASS);
             if (dead_end) after_leaf(-1.0f, -1);                 // same continuation as a fruitless leaf visit
             else if ((nd.b >> 30) == 3u) pending = true;        // a leaf that passed its cull test: scanned in a batch
         }

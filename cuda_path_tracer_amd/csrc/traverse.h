@@ -233,7 +233,7 @@ PT_HD float masked_min(const float tlo[3], const float thi[3]) {
 // scales; for origins farther out the hit parameter t is itself ~|o|/|d| on every axis the ray is not parallel to,
 // and the rounding of P moves the slab parameters by ~1e-7 t, which the 2^-12 (|tf| + 1) widening of the interval
 // test absorbs.  (Parallel axes: P_k = o_k exactly, the box margin alone decides.)
-PT_HD void pair_culled(f4 bx, f4 by, f4 bz, f3 o, f3 d, bool &cull_l, bool &cull_r) {
+PT_HD void pair_culled(f4 bx, f4 by, f4 bz, f3 o, f3 d, bool &cull_l, bool &cull_r, float &near_l, float &near_r) {
     const f4 bb[3] = {bx, by, bz};
     const float oo[3] = {o.x, o.y, o.z}, dd[3] = {d.x, d.y, d.z};
     float tn_l = 0.0f, tf_l = __builtin_inff(), tn_r = 0.0f, tf_r = __builtin_inff();
@@ -256,6 +256,8 @@ PT_HD void pair_culled(f4 bx, f4 by, f4 bz, f3 o, f3 d, bool &cull_l, bool &cull
     // an empty box is stored as (+inf, -inf): its own half turns into NaN / inf and is decided by the last term
     cull_l = out_l | (tn_l > tf_l + 2.44140625e-4f * (fabsf(tf_l) + 1.0f)) | !(bx.x <= bx.z);
     cull_r = out_r | (tn_r > tf_r + 2.44140625e-4f * (fabsf(tf_r) + 1.0f)) | !(bx.y <= bx.w);
+    near_l = tn_l - 2.44140625e-4f * (tn_l + 1.0f);  // lower bounds (tn >= 0) of the parameter of any accepted hit inside
+    near_r = tn_r - 2.44140625e-4f * (tn_r + 1.0f);
 }
 
 // Walks down from `node` for at most max_steps steps; `cur` is a MASKED slab.  Every node this function stands on
@@ -263,9 +265,16 @@ PT_HD void pair_culled(f4 bx, f4 by, f4 bz, f3 o, f3 d, bool &cull_l, bool &cull
 // in is neither entered nor stacked -- visiting it is a no-op in the reference, whatever the order (Q7).  Returns
 // true when nothing below `node` is left to visit (dead end: the caller continues with the stack), false when it
 // stopped on `node` (a leaf, or an interior node if the steps ran out).
+//
+// Distance pruning (scenes with several meshes; t_prune = +inf switches it off): a child whose cull box the ray enters
+// strictly beyond t_prune = the closest answer of the objects evaluated so far can only hold hits that
+// Scene::firstIntersect would not use, so it is treated like a culled child -- but unlike a culled child it may hold
+// the accepted hit at which the reference ENDS this mesh's search (Q8).  `taint_bit` of `flags` records that such a
+// child was dropped; if the search then still comes up with a hit that would be used, the caller repeats the mesh without
+// pruning (rare: it takes a leaf order that is not front to back).
 template <class Stack>
 PT_HD bool descend_fast(const DScene &sc, f3 o, f3 d, SlabBox &cur, int &node, KdNode &nd, int &sp, Stack &stk,
-                        int max_steps PSTAT_ARG) {
+                        int max_steps, bool prune, float t_prune, uint32_t &flags, uint32_t taint_bit PSTAT_ARG) {
     const float inf = __builtin_inff();
     for (int step = 0; (nd.b >> 30) != 3u && step < max_steps; step++) {
         PSTAT(ps, 9);
@@ -276,7 +285,14 @@ PT_HD bool descend_fast(const DScene &sc, f3 o, f3 d, SlabBox &cur, int &node, K
         const f4 *tb = sc.tight_pairs + 2 * (size_t)left;  // 4 float4 per sibling pair, pair index = left / 2
         const f4 tbx = tb[0], tby = tb[1], tbz = tb[2];
         bool cull_l, cull_r;
-        pair_culled(tbx, tby, tbz, o, d, cull_l, cull_r);
+        float near_l, near_r;
+        pair_culled(tbx, tby, tbz, o, d, cull_l, cull_r, near_l, near_r);
+        if (prune) {  // wave-uniform
+            const bool far_l = near_l > t_prune, far_r = near_r > t_prune;
+            flags |= ((far_l & !cull_l) | (far_r & !cull_r)) ? taint_bit : 0u;
+            cull_l |= far_l;
+            cull_r |= far_r;
+        }
         if (cull_l & cull_r) return true;
 
         const float s = as_f32(nd.a);
