@@ -470,7 +470,7 @@ bool HostScene::pack(int n_threads, std::string &err) {
         // leaf-ordered candidate spheres (no counterpart in the reference; they change no result): a hit the leaf
         // loop accepts lies on the triangle (up to the rounding of the edge tests) and inside the leaf box (up to its
         // 1e-5 slack), i.e. inside both the triangle's smallest enclosing sphere and the sphere around
-        // AABB(triangle) ∩ cull box of the leaf.  The smaller of the two, grown by 2^-10 relative + 2^-13 x (largest
+        // AABB(triangle) ∩ cull box of the leaf.  The smaller of the two, grown by 2^-10 relative + 4e-5 + 2^-16 x (largest
         // coordinate, at least 1) absolute, is what leaf_scan() tests the ray against before it evaluates a candidate.
         float *ls = reinterpret_cast<float *>(A + L.leaf_spheres);  // indexed by GLOBAL reference (pairs interleaved)
         parallel_for(hm.n_nodes, n_threads, [&](int64_t i_begin, int64_t i_end) {
@@ -542,7 +542,11 @@ bool HostScene::pack(int n_threads, std::string &err) {
                     }
                 }
                 if (!std::isfinite(mag)) mag = 1.0;
-                const double R = std::sqrt(rad2) * (1.0 + 1.0 / 1024.0) + mag / 8192.0;
+                // margin: sqrt(3) x the 1e-5 box slack (1.8e-5) + the rounding of P = o + d t and of the edge tests (a few
+                // ulp of the coordinates, < 1e-6 x mag for origins within the scene's scale; leaf_scan() adds a term for
+                // far origins) -- covered 2x and 15x by 4e-5 + 2^-16 mag.  (2^-13 mag, the first choice, made the spheres
+                // of a 1.3 M-triangle mesh 10 % wider than the triangles need: 15 % more candidates to evaluate.)
+                const double R = std::sqrt(rad2) * (1.0 + 1.0 / 1024.0) + 4e-5 + mag / 65536.0;
                 float R2 = (float)(R * R);
                 R2 = std::nextafter(R2, INFINITY);
                 if (!(R2 >= 0.0f) || !std::isfinite(R2) || !std::isfinite(cen[0]) || !std::isfinite(cen[1]) || !std::isfinite(cen[2])) {
