@@ -214,6 +214,7 @@ int mipt_scene_commit(mipt_scene *s, const int *device_ids, int n_devices) {
         dc.extend_blocks_per_cu = query_extend_blocks_per_cu();
         const char *ev = getenv("MIPT_EXTEND");
         dc.extend_simple = ev && std::string(ev) == "simple";
+        if (const char *sv = getenv("MIPT_SHADOW_SORT")) dc.shadow_sort_from = atoi(sv);
         if (const char *tv = getenv("MIPT_TUNE")) sscanf(tv, "%d,%d,%d", &dc.tune.refill_lanes, &dc.tune.leaf_batch_lanes, &dc.tune.step_cap);
         dc.view = s->host.view(dc.arena);
         s->devs.push_back(dc);

@@ -70,10 +70,11 @@ struct DeviceCtx {
     int extend_blocks_per_cu = 4;  // resident blocks of the persistent extend kernel
     ExtendTuning tune;
     bool extend_simple = false;    // MIPT_EXTEND=simple: grid-stride reference kernel (A/B timing)
+    int shadow_sort_from = 1;      // MIPT_SHADOW_SORT=<vertex>: first camera vertex whose shadow rays are binned by direction (-1: never)
     // closest-hit work buffers
     DevBuf ray_o, ray_d, hits, io_a, io_b, io_c, io_d, counters;
     // wavefront work buffers (see wavefront.hip)
-    DevBuf wf[32];
+    DevBuf wf[36];
     EventPool events;
 };
 
