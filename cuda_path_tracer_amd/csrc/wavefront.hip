@@ -103,9 +103,18 @@ __device__ __forceinline__ uint32_t direction_cell(f3 d) {
         w = (1.0f - fabsf(u)) * (w >= 0.0f ? 1.0f : -1.0f);
         u = uu;
     }
-    const int iu = min(255, max(0, (int)((u * 0.5f + 0.5f) * 256.0f))), iw = min(255, max(0, (int)((w * 0.5f + 0.5f) * 256.0f)));
-    return (uint32_t)(iu * 256 + iw);
+    const int iu = min(4095, max(0, (int)((u * 0.5f + 0.5f) * 4096.0f))), iw = min(4095, max(0, (int)((w * 0.5f + 0.5f) * 4096.0f)));
+    auto spread = [](uint32_t x) {  // 12 bits -> every other bit of 24
+        x = (x | (x << 8)) & 0x00ff00ffu;
+        x = (x | (x << 4)) & 0x0f0f0f0fu;
+        x = (x | (x << 2)) & 0x33333333u;
+        x = (x | (x << 1)) & 0x55555555u;
+        return x;
+    };
+    return spread((uint32_t)iu) | (spread((uint32_t)iw) << 1);  // Morton order: consecutive keys = a compact patch of directions
 }
+
+constexpr unsigned kShadowKeyBits = 24;
 
 struct PassParams {
     int W, H, npix;
@@ -613,7 +622,7 @@ int wavefront_render(const HostScene &hs, DeviceCtx &dc, const mipt_render_confi
     if (sort_shadow) {
         sizes[30] = sizes[31] = sizes[32] = P * 4;
         WF_TRY(rocprim::radix_sort_pairs(nullptr, sort_temp_bytes, (uint32_t *)nullptr, (uint32_t *)nullptr, (int *)nullptr,
-                                         (int *)nullptr, P, 0, 16, dc.stream));
+                                         (int *)nullptr, P, 0, kShadowKeyBits, dc.stream));
         sizes[33] = sort_temp_bytes;
     }
     static_assert(sizeof(dc.wf) / sizeof(dc.wf[0]) >= 34, "wf buffer table too small");
@@ -688,7 +697,7 @@ int wavefront_render(const HostScene &hs, DeviceCtx &dc, const mipt_render_confi
                 if (n_sh > 1) {
                     size_t tb = sort_temp_bytes;
                     WF_TRY(rocprim::radix_sort_pairs(dc.wf[33].p, tb, b.q_shadow_key, dc.wf[31].as<uint32_t>(), b.q_shadow,
-                                                     dc.wf[32].as<int>(), (size_t)n_sh, 0, 16, sm));
+                                                     dc.wf[32].as<int>(), (size_t)n_sh, 0, kShadowKeyBits, sm));
                     shadow_queue = dc.wf[32].as<int>();
                 }
             }
