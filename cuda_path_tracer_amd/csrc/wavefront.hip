@@ -79,7 +79,7 @@ __device__ __forceinline__ int wave_sum_i(int v) {
 // box that answer is final, else queue the ray for extend.  Call it from block-convergent code.  Returns true when the
 // ray was decided here (callers tally those).
 __device__ __forceinline__ bool emit_ray(const DScene &sc, bool valid, f3 o, f3 d, HitRec *hit_slot, int queue_value, int *queue,
-                                         int *queue_count, int *lds, int &phase) {
+                                         int *queue_count, int *lds, int &phase, uint32_t *keys = nullptr, uint32_t key = 0u) {
     bool need_extend = false;
     if (valid) {
         HitRec h;
@@ -88,7 +88,10 @@ __device__ __forceinline__ bool emit_ray(const DScene &sc, bool valid, f3 o, f3 
         need_extend = !misses_every_mesh(sc, o, d);
     }
     const int qi = block_append(need_extend, queue_count, lds, phase);
-    if (need_extend) queue[qi] = queue_value;
+    if (need_extend) {
+        queue[qi] = queue_value;
+        if (keys) keys[qi] = key;  // sort key of the queue entry (see wavefront_render)
+    }
     return valid && !need_extend;
 }
 
@@ -115,6 +118,7 @@ __device__ __forceinline__ uint32_t direction_cell(f3 d) {
 }
 
 constexpr unsigned kShadowKeyBits = 24;
+constexpr uint32_t kKeyLast = (1u << kShadowKeyBits) - 1u;  // rays that are not binned keep their order behind the binned ones
 
 struct PassParams {
     int W, H, npix;
@@ -156,7 +160,9 @@ struct WfBuffers {
     HitRec *sh_hit;
     int *q_cam0;                 // bidirectional only: path ids whose camera path is traced (Q11); vertex 0 is indexed by path id
     int *q_light[2], *q_shadow;  // light-path bookkeeping / shadow rays to trace
-    uint32_t *q_shadow_key;      // simple integrator: direction cell of each queued shadow ray (see direction_cell), or null
+    uint32_t *q_shadow_key;      // direction cell of each queued direct-connection ray (see direction_cell); connection rays to
+                                 // light vertices get kKeyLast; or null
+    uint32_t *q_light_key;       // light index << 24 | direction cell of each queued first light ray, or null
     int *q_ext_cam, *q_ext_light;           // the subset of camera / light rays that needs the extend kernel
     int *counts;                 // per-stage queue counts of the current pass
     unsigned long long *totals;  // [0] camera rays [1] shadow rays [2] light rays [3] rays traced by k_extend
@@ -216,12 +222,14 @@ __global__ __launch_bounds__(kBlock) void k_lightgen(DScene sc, PassParams pp, W
     const int n = pp.n_slots * pp.npix;
     const bool live = pid < n;
     f3 lo = mk3(0.f, 0.f, 0.f), ld = mk3(0.f, 0.f, 1.f);
+    int li_key = 0;
     if (live) {
         const int slot = pid / pp.npix, pixel = pixel_of(pp, pid - slot * pp.npix);
         Rng rng;
         rng.init(pp.seed, (uint32_t)pixel, (uint32_t)(pp.sample0 + slot * pp.sample_stride), b.path_rng[pid]);
         int li = (int)(rng.u() * ((float)sc.n_lights));  // kernel.cu:178
         if (li >= sc.n_lights) li = sc.n_lights - 1;      // Q17 clamp
+        li_key = li;
         const f3 ldir = light_sample_dir(rng);
         lo = xyz(sc.lights[2 * li]);
         ld = norm3(ldir);                                 // Ray ctor normalises again (ray.cuh:10)
@@ -235,7 +243,7 @@ __global__ __launch_bounds__(kBlock) void k_lightgen(DScene sc, PassParams pp, W
         }
     }
     (void)emit_ray(sc, live, lo, ld, live ? &b.l_hit[pid] : nullptr, pid, b.q_ext_light, &b.counts[kCntPad * (kCntExtLight + 0)],
-                   ap_lds, phase);
+                   ap_lds, phase, b.q_light_key, b.q_light_key ? ((uint32_t)min(li_key, 255) << 24) | direction_cell(ld) : 0u);
 }
 
 // light sub-path vertex i (kernel.cu:184-231)
@@ -468,7 +476,7 @@ __global__ __launch_bounds__(kBlock) void k_shade(DScene sc, PassParams pp, WfBu
             const size_t si = emit ? (size_t)j * pp.K + k : 0;
             const f3 so = emit ? xyz(b.sh_o[si]) : nro, sd = emit ? xyz(b.sh_d[si]) : nrd;
             if (emit_ray(sc, emit, so, sd, emit ? &b.sh_hit[si] : nullptr, (int)si, b.q_shadow,
-                         &b.counts[kCntPad * (kCntShadow + i)], ap_lds, phase))
+                         &b.counts[kCntPad * (kCntShadow + i)], ap_lds, phase, b.q_shadow_key, kKeyLast))
                 n_trivial++;
         }
     }
@@ -617,16 +625,19 @@ int wavefront_render(const HostScene &hs, DeviceCtx &dc, const mipt_render_confi
         sizes[25] = sizes[26] = sizes[27] = sizes[28] = sizes[29] = P * 4;  // path_rng, q_cam0, q_light[2], q_ext_light
     }
     // direction binning of the shadow rays (simple integrator, persistent kernel): keys in / out, sorted queue, scratch
-    const bool sort_shadow = (K == 1) && !dc.extend_simple && dc.shadow_sort_from >= 0 && dc.shadow_sort_from < Dc;
+    // (not worth its ~1 ms + host round trip per queue when the trees are a few nodes deep: default scene, 36 triangles)
+    const bool sort_shadow = !dc.extend_simple && dc.shadow_sort_from >= 0 && dc.shadow_sort_from < Dc && hs.total_tris >= 4096;
+    const bool sort_light = sort_shadow && Dl > 0;  // first light rays: binned by (light, direction)
     size_t sort_temp_bytes = 0;
     if (sort_shadow) {
-        sizes[30] = sizes[31] = sizes[32] = P * 4;
+        sizes[30] = sizes[31] = sizes[32] = P * K * 4;  // keys in / keys out (scratch) / sorted queue
         WF_TRY(rocprim::radix_sort_pairs(nullptr, sort_temp_bytes, (uint32_t *)nullptr, (uint32_t *)nullptr, (int *)nullptr,
-                                         (int *)nullptr, P, 0, kShadowKeyBits, dc.stream));
+                                         (int *)nullptr, P * K, 0, 32, dc.stream));
         sizes[33] = sort_temp_bytes;
+        if (sort_light) sizes[34] = P * 4;
     }
-    static_assert(sizeof(dc.wf) / sizeof(dc.wf[0]) >= 34, "wf buffer table too small");
-    for (int i = 0; i < 34; i++)
+    static_assert(sizeof(dc.wf) / sizeof(dc.wf[0]) >= 35, "wf buffer table too small");
+    for (int i = 0; i < 35; i++)
         if (sizes[i]) WF_TRY(dc.wf[i].reserve(sizes[i]));
     WfBuffers b;
     memset(&b, 0, sizeof(b));
@@ -644,6 +655,7 @@ int wavefront_render(const HostScene &hs, DeviceCtx &dc, const mipt_render_confi
     b.path_rng = dc.wf[25].as<uint32_t>(); b.q_cam0 = dc.wf[26].as<int>();
     b.q_light[0] = dc.wf[27].as<int>(); b.q_light[1] = dc.wf[28].as<int>(); b.q_ext_light = dc.wf[29].as<int>();
     b.q_shadow_key = sort_shadow ? dc.wf[30].as<uint32_t>() : nullptr;
+    b.q_light_key = sort_light ? dc.wf[34].as<uint32_t>() : nullptr;
 
     dc.events.reset();
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ext_ev;
@@ -654,6 +666,19 @@ int wavefront_render(const HostScene &hs, DeviceCtx &dc, const mipt_render_confi
     hipEvent_t ev_begin = dc.events.next(), ev_end = dc.events.next();
     WF_TRY(hipEventRecord(ev_begin, sm));
 
+    // Stable radix sort of a ray queue by its keys into wf[32]; `queue` then points at the sorted copy.  The sort needs
+    // the queue length on the host: the one kind of host round trip inside a pass (4 bytes, ~20 us).
+    auto sort_queue = [&](const uint32_t *keys, const int *queue_in, int count_slot, unsigned key_bits, const int *&queue) {
+        int n_q = 0;
+        hipError_t e = hipMemcpyAsync(&n_q, &b.counts[kCntPad * count_slot], sizeof(int), hipMemcpyDeviceToHost, sm);
+        if (e == hipSuccess) e = hipStreamSynchronize(sm);
+        if (e != hipSuccess || n_q <= 1) return e;
+        size_t tb = sort_temp_bytes;
+        e = rocprim::radix_sort_pairs(dc.wf[33].p, tb, keys, dc.wf[31].as<uint32_t>(), queue_in, dc.wf[32].as<int>(), (size_t)n_q, 0,
+                                      key_bits, sm);
+        if (e == hipSuccess) queue = dc.wf[32].as<int>();
+        return e;
+    };
     int n_launch = 0;
     auto extend = [&](const f4 *ro, const f4 *rd, const int *queue, const int *count, HitRec *hits, size_t n_max) {
         hipEvent_t a = dc.events.next(), e = dc.events.next();
@@ -681,7 +706,13 @@ int wavefront_render(const HostScene &hs, DeviceCtx &dc, const mipt_render_confi
         if (Dl > 0) {
             hipLaunchKernelGGL(k_lightgen, dim3(full_grid), dim3(kBlock), 0, sm, dc.view, pp, b);
             for (int i = 0; i < Dl; i++) {
-                extend(b.l_o, b.l_d, b.q_ext_light, &b.counts[kCntPad * (kCntExtLight + i)], b.l_hit, np);
+                const int *light_queue = b.q_ext_light;
+                if (sort_light && i == 0) {
+                    unsigned light_bits = 0;
+                    while ((1 << light_bits) < std::min<int>((int)hs.lights.size(), 256)) light_bits++;
+                    WF_TRY(sort_queue(b.q_light_key, b.q_ext_light, kCntExtLight + 0, kShadowKeyBits + light_bits, light_queue));
+                }
+                extend(b.l_o, b.l_d, light_queue, &b.counts[kCntPad * (kCntExtLight + i)], b.l_hit, np);
                 hipLaunchKernelGGL(k_light_shade, dim3(path_grid), dim3(kBlock), 0, sm, dc.view, pp, b, i);
             }
         }
@@ -689,18 +720,8 @@ int wavefront_render(const HostScene &hs, DeviceCtx &dc, const mipt_render_confi
             extend(b.st_o[i & 1], b.st_d[i & 1], b.q_ext_cam, &b.counts[kCntPad * (kCntExtCam + i)], b.st_hit[i & 1], np);
             hipLaunchKernelGGL(k_shade, dim3(path_grid), dim3(kBlock), 0, sm, dc.view, pp, b, i);
             const int *shadow_queue = b.q_shadow;
-            if (sort_shadow && i >= dc.shadow_sort_from) {
-                // the one host round trip of a pass: the sort needs the queue length on the host (4 bytes, ~20 us)
-                int n_sh = 0;
-                WF_TRY(hipMemcpyAsync(&n_sh, &b.counts[kCntPad * (kCntShadow + i)], sizeof(int), hipMemcpyDeviceToHost, sm));
-                WF_TRY(hipStreamSynchronize(sm));
-                if (n_sh > 1) {
-                    size_t tb = sort_temp_bytes;
-                    WF_TRY(rocprim::radix_sort_pairs(dc.wf[33].p, tb, b.q_shadow_key, dc.wf[31].as<uint32_t>(), b.q_shadow,
-                                                     dc.wf[32].as<int>(), (size_t)n_sh, 0, kShadowKeyBits, sm));
-                    shadow_queue = dc.wf[32].as<int>();
-                }
-            }
+            if (sort_shadow && i >= dc.shadow_sort_from)
+                WF_TRY(sort_queue(b.q_shadow_key, b.q_shadow, kCntShadow + i, kShadowKeyBits, shadow_queue));
             extend(b.sh_o, b.sh_d, shadow_queue, &b.counts[kCntPad * (kCntShadow + i)], b.sh_hit, np * K);
             hipLaunchKernelGGL(k_resolve, dim3(path_grid), dim3(kBlock), 0, sm, dc.view, pp, b, i);
             // the shadow queue is refilled from slot 0 by the next vertex: its count lives in its own slot

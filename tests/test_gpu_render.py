@@ -200,3 +200,26 @@ def test_coincident_meshes_render_bit_exact():
         img, _ = s.render(cfg)
         ref, _ = o.render(cfg)
         assert np.array_equal(img.view(np.uint32), ref.view(np.uint32))
+
+
+def test_ray_binning_changes_no_result(monkeypatch):
+    """Shadow / first light rays are radix-sorted by direction before the closest-hit kernel (scenes >= 4096 triangles;
+    MIPT_SHADOW_SORT=-1, read at commit, switches it off): same images bit for bit, same ray counts, equal to the oracle."""
+    desc = G.scene_icosphere_room(5)  # 20,480 triangles
+    binned = desc.apply(Scene())
+    binned.commit(devices=(0,))
+    monkeypatch.setenv("MIPT_SHADOW_SORT", "-1")
+    plain = desc.apply(Scene())
+    plain.commit(devices=(0,))
+    monkeypatch.delenv("MIPT_SHADOW_SORT")
+    o = desc.apply(OracleScene())
+    o.commit()
+    for cfg in (make_config(96, 64, spp=4, cam_depth=6, light_depth=0), make_config(64, 48, spp=3, cam_depth=4, light_depth=3)):
+        a, sa = binned.render(cfg)
+        b, sb = plain.render(cfg)
+        ref, _ = o.render(cfg)
+        assert a.max() > 0.01
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+        assert np.array_equal(a.view(np.uint32), ref.view(np.uint32))
+        for k in ("rays_total", "rays_shadow", "rays_camera", "rays_light", "rays_extended", "samples"):
+            assert sa[k] == sb[k], k
