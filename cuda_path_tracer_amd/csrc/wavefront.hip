@@ -69,6 +69,50 @@ __device__ __forceinline__ int block_append(bool pred, int *counter, int *lds, i
     return pred ? slot[wave] + rank : -1;
 }
 
+// Three appends at once (k_shade: next-vertex state, camera-ray queue, shadow-ray queue): one barrier pair and three
+// atomics IN FLIGHT TOGETHER instead of three barrier pairs around three atomic round trips, during each of which the
+// whole block waits.  Wave 0 scans the three per-wave count vectors in 8-lane segments.  `lds`: 2 * 3 * kWaves ints.
+struct Idx3 {
+    int a, b, c;
+};
+__device__ __forceinline__ Idx3 block_append3(bool pa, bool pb, bool pc, int *ca, int *cb, int *cc, int *lds, int &phase) {
+    static_assert(kWaves == 8, "8-lane segments");
+    int *slot = lds + phase * (3 * kWaves);
+    phase ^= 1;
+    const unsigned long long ma = __ballot(pa), mb = __ballot(pb), mc = __ballot(pc);
+    const int lane = (int)(threadIdx.x & 63u), wave = (int)(threadIdx.x >> 6);
+    if (lane == 0) {
+        slot[wave] = __popcll(ma);
+        slot[kWaves + wave] = __popcll(mb);
+        slot[2 * kWaves + wave] = __popcll(mc);
+    }
+    __syncthreads();
+    if (wave == 0) {
+        const int seg = lane >> 3, l = lane & 7;
+        const int c = lane < 3 * kWaves ? slot[lane] : 0;
+        int incl = c;
+#pragma unroll
+        for (int off = 1; off < kWaves; off <<= 1) {
+            const int t = __shfl_up(incl, off, 64);
+            if (l >= off) incl += t;
+        }
+        const int total = __shfl(incl, lane | 7, 64);
+        int base = 0;
+        if (l == 0 && lane < 3 * kWaves && total > 0) base = atomicAdd(seg == 0 ? ca : (seg == 1 ? cb : cc), total);
+        base = __shfl(base, lane & ~7, 64);
+        if (lane < 3 * kWaves) slot[lane] = base + incl - c;
+    }
+    __syncthreads();
+    auto rank = [](unsigned long long m) {
+        return (int)__builtin_amdgcn_mbcnt_hi((unsigned int)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)m, 0u));
+    };
+    Idx3 r;
+    r.a = pa ? slot[wave] + rank(ma) : -1;
+    r.b = pb ? slot[kWaves + wave] + rank(mb) : -1;
+    r.c = pc ? slot[2 * kWaves + wave] + rank(mc) : -1;
+    return r;
+}
+
 __device__ __forceinline__ int wave_sum_i(int v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
@@ -329,7 +373,8 @@ __global__ __launch_bounds__(kBlock) void k_light_shade(DScene sc, PassParams pp
 // camera sub-path vertex i (kernel.cu:239-303)
 __global__ __launch_bounds__(kBlock) void k_shade(DScene sc, PassParams pp, WfBuffers b, int i) {
     __shared__ int ap_lds[2 * (kWaves + 1)];
-    int phase = 0;
+    __shared__ int ap3_lds[2 * 3 * kWaves];
+    int phase = 0, phase3 = 0;
     int n_trivial = 0;  // shadow rays answered here; one atomic per wave at the end
     const int n = b.counts[kCntPad * (kCntCam + i)];
     const int par = i & 1;
@@ -430,28 +475,36 @@ __global__ __launch_bounds__(kBlock) void k_shade(DScene sc, PassParams pp, WfBu
                 }
             }
         }
-        // a continuing path takes its rank among the block's continuing paths as its index at the next vertex
-        const int qi = block_append(cont, &b.counts[kCntPad * (kCntCam + i + 1)], ap_lds, phase);
-        if (cont) {
-            b.st_o[par ^ 1][qi] = mk4(nro, as_f32(draw));
-            b.st_d[par ^ 1][qi] = mk4(nrd, as_f32((uint32_t)pid));
-            b.st_T[par ^ 1][qi] = mk4(Tc, pc);
-        }
-        (void)emit_ray(sc, cont, nro, nrd, cont ? &b.st_hit[par ^ 1][qi] : nullptr, qi, b.q_ext_cam,
-                       &b.counts[kCntPad * (kCntExtCam + i + 1)], ap_lds, phase);
-        {   // direct connection: answered and resolved here when it misses every mesh's root cull box (52 % of them
-            // in the box-room scenes), else staged for the extend kernel and k_resolve
+        {
+            // the two rays this vertex makes: the next camera ray and the direct connection.  Their sphere / plane
+            // answers are taken here (convergent lanes); a ray that misses every mesh's root cull box is finished
+            // (52 % of them in the box-room scenes), the others are queued for the extend kernel.
             const f3 lp = xyz(sc.lights[0]);
             const size_t si = (size_t)j * pp.K;
-            HitRec sh;
-            sh.t = -1.0f;
-            sh.prim = -1;
-            bool need_extend = false;
+            HitRec ch, sh;
+            ch.t = sh.t = -1.0f;
+            ch.prim = sh.prim = -1;
+            bool cam_extend = false, need_extend = false;
+            if (cont) {
+                quadrics_closest(sc, nro, nrd, ch.t, ch.prim);
+                cam_extend = !misses_every_mesh(sc, nro, nrd);
+            }
             if (direct) {
                 quadrics_closest(sc, lp, dr_d, sh.t, sh.prim);
                 need_extend = !misses_every_mesh(sc, lp, dr_d);
             }
-            const int qi = block_append(need_extend, &b.counts[kCntPad * (kCntShadow + i)], ap_lds, phase);
+            // a continuing path takes its rank among the block's continuing paths as its index at the next vertex
+            const Idx3 at = block_append3(cont, cam_extend, need_extend, &b.counts[kCntPad * (kCntCam + i + 1)],
+                                          &b.counts[kCntPad * (kCntExtCam + i + 1)], &b.counts[kCntPad * (kCntShadow + i)],
+                                          ap3_lds, phase3);
+            if (cont) {
+                b.st_o[par ^ 1][at.a] = mk4(nro, as_f32(draw));
+                b.st_d[par ^ 1][at.a] = mk4(nrd, as_f32((uint32_t)pid));
+                b.st_T[par ^ 1][at.a] = mk4(Tc, pc);
+                b.st_hit[par ^ 1][at.a] = ch;
+            }
+            if (cam_extend) b.q_ext_cam[at.b] = at.a;
+            const int qi = at.c;
             if (need_extend) {
                 b.q_shadow[qi] = (int)si;
                 if (b.q_shadow_key) b.q_shadow_key[qi] = direction_cell(dr_d);
