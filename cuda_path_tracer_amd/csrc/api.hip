@@ -216,6 +216,8 @@ int mipt_scene_commit(mipt_scene *s, const int *device_ids, int n_devices) {
         dc.extend_simple = ev && std::string(ev) == "simple";
         if (const char *sv = getenv("MIPT_SHADOW_SORT")) dc.shadow_sort_from = atoi(sv);
         if (const char *tv = getenv("MIPT_TUNE")) sscanf(tv, "%d,%d,%d", &dc.tune.refill_lanes, &dc.tune.leaf_batch_lanes, &dc.tune.step_cap);
+        if (const char *tv = getenv("MIPT_TUNE_COHERENT"))
+            sscanf(tv, "%d,%d,%d", &dc.tune_coherent.refill_lanes, &dc.tune_coherent.leaf_batch_lanes, &dc.tune_coherent.step_cap);
         dc.view = s->host.view(dc.arena);
         s->devs.push_back(dc);
     }

@@ -331,7 +331,8 @@ static __global__ __launch_bounds__(256) void k_split_hits(const HitRec *__restr
 
 // Launch the extend stage on dc.stream.  `work` must point at a zeroed int (the persistent kernel's ray cursor).
 inline void launch_extend(const DeviceCtx &dc, bool count, const f4 *ro, const f4 *rd, const int *queue, const int *count_ptr,
-                          int n_fixed, int64_t n_max, HitRec *hits, int *work, unsigned long long *ctr) {
+                          int n_fixed, int64_t n_max, HitRec *hits, int *work, unsigned long long *ctr, bool coherent_queue = false) {
+    const ExtendTuning tune = coherent_queue ? dc.tune_coherent : dc.tune;
     if (dc.extend_simple) {
         const int64_t want = (n_max + kExtendBlock - 1) / kExtendBlock;
         const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(want, (int64_t)dc.num_cus * 8));
@@ -347,10 +348,10 @@ inline void launch_extend(const DeviceCtx &dc, bool count, const f4 *ro, const f
     const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(want, (int64_t)dc.num_cus * dc.extend_blocks_per_cu));
     if (count)
         hipLaunchKernelGGL(k_extend<true>, dim3(grid), dim3(kExtendBlock), 0, dc.stream, dc.view, ro, rd, queue, count_ptr,
-                           n_fixed, hits, work, ctr, dc.tune);
+                           n_fixed, hits, work, ctr, tune);
     else
         hipLaunchKernelGGL(k_extend<false>, dim3(grid), dim3(kExtendBlock), 0, dc.stream, dc.view, ro, rd, queue, count_ptr,
-                           n_fixed, hits, work, ctr, dc.tune);
+                           n_fixed, hits, work, ctr, tune);
 }
 
 // Resident 256-thread blocks per CU of the persistent kernel (occupancy API, capped like the hardware admits).

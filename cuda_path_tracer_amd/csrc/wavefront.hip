@@ -733,11 +733,11 @@ int wavefront_render(const HostScene &hs, DeviceCtx &dc, const mipt_render_confi
         return e;
     };
     int n_launch = 0;
-    auto extend = [&](const f4 *ro, const f4 *rd, const int *queue, const int *count, HitRec *hits, size_t n_max) {
+    auto extend = [&](const f4 *ro, const f4 *rd, const int *queue, const int *count, HitRec *hits, size_t n_max, bool coherent_queue) {
         hipEvent_t a = dc.events.next(), e = dc.events.next();
         (void)hipEventRecord(a, sm);
         launch_extend(dc, count_mode, ro, rd, queue, count, 0, (int64_t)n_max, hits, &b.counts[kCntPad * (kCntWork + (n_launch++))],
-                      dc.counters.as<unsigned long long>());
+                      dc.counters.as<unsigned long long>(), coherent_queue);
         (void)hipEventRecord(e, sm);
         ext_ev.emplace_back(a, e);
     };
@@ -765,17 +765,18 @@ int wavefront_render(const HostScene &hs, DeviceCtx &dc, const mipt_render_confi
                     while ((1 << light_bits) < std::min<int>((int)hs.lights.size(), 256)) light_bits++;
                     WF_TRY(sort_queue(b.q_light_key, b.q_ext_light, kCntExtLight + 0, kShadowKeyBits + light_bits, light_queue));
                 }
-                extend(b.l_o, b.l_d, light_queue, &b.counts[kCntPad * (kCntExtLight + i)], b.l_hit, np);
+                extend(b.l_o, b.l_d, light_queue, &b.counts[kCntPad * (kCntExtLight + i)], b.l_hit, np, light_queue != b.q_ext_light);
                 hipLaunchKernelGGL(k_light_shade, dim3(path_grid), dim3(kBlock), 0, sm, dc.view, pp, b, i);
             }
         }
         for (int i = 0; i < Dc; i++) {
-            extend(b.st_o[i & 1], b.st_d[i & 1], b.q_ext_cam, &b.counts[kCntPad * (kCntExtCam + i)], b.st_hit[i & 1], np);
+            extend(b.st_o[i & 1], b.st_d[i & 1], b.q_ext_cam, &b.counts[kCntPad * (kCntExtCam + i)], b.st_hit[i & 1], np, i == 0);
             hipLaunchKernelGGL(k_shade, dim3(path_grid), dim3(kBlock), 0, sm, dc.view, pp, b, i);
             const int *shadow_queue = b.q_shadow;
             if (sort_shadow && i >= dc.shadow_sort_from)
                 WF_TRY(sort_queue(b.q_shadow_key, b.q_shadow, kCntShadow + i, kShadowKeyBits, shadow_queue));
-            extend(b.sh_o, b.sh_d, shadow_queue, &b.counts[kCntPad * (kCntShadow + i)], b.sh_hit, np * K);
+            extend(b.sh_o, b.sh_d, shadow_queue, &b.counts[kCntPad * (kCntShadow + i)], b.sh_hit, np * K,
+                   K == 1 && (i == 0 || shadow_queue != b.q_shadow));  // (K > 1: mostly connection rays, in path order)
             hipLaunchKernelGGL(k_resolve, dim3(path_grid), dim3(kBlock), 0, sm, dc.view, pp, b, i);
             // the shadow queue is refilled from slot 0 by the next vertex: its count lives in its own slot
         }
