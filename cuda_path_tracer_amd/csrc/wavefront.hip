@@ -789,6 +789,21 @@ int wavefront_render(const HostScene &hs, DeviceCtx &dc, const mipt_render_confi
 #ifdef MIPT_PHASE_STATS
     if (!count_mode) dump_phase_stats(dc, "render");
 #endif
+    if (getenv("MIPT_TIMING")) {  // queue lengths of the last pass and the duration of every extend launch, in launch order
+        std::vector<int> cnt((size_t)kCntTotal * kCntPad);
+        WF_TRY(hipMemcpy(cnt.data(), b.counts, cnt.size() * sizeof(int), hipMemcpyDeviceToHost));
+        fprintf(stderr, "[mipt] last pass, per camera vertex: alive / camera rays through extend / shadow rays through extend / answered on the spot\n");
+        for (int i = 0; i < Dc; i++)
+            fprintf(stderr, "[mipt]   vertex %d: %d / %d / %d / %d\n", i, cnt[(size_t)kCntPad * (kCntCam + i)], cnt[(size_t)kCntPad * (kCntExtCam + i)],
+                    cnt[(size_t)kCntPad * (kCntShadow + i)], cnt[(size_t)kCntPad * (kCntShadowTriv + i)]);
+        fprintf(stderr, "[mipt] extend launches (ms):");
+        for (size_t k = ext_ev.size() >= (size_t)n_launch ? ext_ev.size() - (size_t)n_launch : 0; k < ext_ev.size(); k++) {
+            float m = 0.f;
+            (void)hipEventElapsedTime(&m, ext_ev[k].first, ext_ev[k].second);
+            fprintf(stderr, " %.2f", m);
+        }
+        fprintf(stderr, "\n");
+    }
     if (st) {
         unsigned long long tot[4] = {0, 0, 0, 0};
         WF_TRY(hipMemcpy(tot, b.totals, sizeof(tot), hipMemcpyDeviceToHost));

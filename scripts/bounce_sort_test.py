@@ -8,9 +8,10 @@ from cuda_path_tracer_amd.scene import Scene
 desc = G.scene_icosphere_room(6)
 s = desc.apply(Scene()); s.commit((0,))
 W, H = 1920, 1080
+SPP = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 ro, rd = G.camera_rays(desc.camera, W, H, W * H)
 idx = np.arange(W * H).reshape(H // 8, 8, W // 8, 8).transpose(0, 2, 1, 3).reshape(-1)
-ro, rd = ro[idx], rd[idx]
+ro, rd = np.tile(ro[idx], (SPP, 1)), np.tile(rd[idx], (SPP, 1))  # SPP sample slots, tile order inside each (as in a pass)
 c = np.array([0, -1, -2], np.float32)
 rng = np.random.Generator(np.random.Philox(key=3))
 
@@ -79,6 +80,13 @@ orders = [("as generated", np.arange(m)),
           ("morton 4b, dir 8x8", np.argsort(morton(o, 4) * 64 + dir_cell(d, 8), kind="stable")),
           ("dir 8x8, morton 5b", np.argsort(dir_cell(d, 8) * (1 << 15) + morton(o, 5), kind="stable")),
           ("dir 16x16, morton 6b", np.argsort(dir_cell(d, 16) * (1 << 18) + morton(o, 6), kind="stable")),
+          ("morton 5b, dir 8x8", np.argsort(morton(o, 5) * 64 + dir_cell(d, 8), kind="stable")),
+          ("morton 6b, dir 8x8", np.argsort(morton(o, 6) * 64 + dir_cell(d, 8), kind="stable")),
+          ("morton 7b, dir 8x8", np.argsort(morton(o, 7) * 64 + dir_cell(d, 8), kind="stable")),
+          ("morton 5b, dir 16x16", np.argsort(morton(o, 5) * 256 + dir_cell(d, 16), kind="stable")),
+          ("morton 6b, dir 16x16", np.argsort(morton(o, 6) * 256 + dir_cell(d, 16), kind="stable")),
+          ("morton 4b, dir 32x32", np.argsort(morton(o, 4) * 1024 + dir_cell(d, 32), kind="stable")),
+          ("dir 8x8, morton 7b", np.argsort(dir_cell(d, 8) * (1 << 21) + morton(o, 7), kind="stable")),
           ("shuffled", rng.permutation(m))]
 d_p = torch.empty(m, dtype=torch.int32, device="cuda"); d_t = torch.empty(m, dtype=torch.float32, device="cuda")
 for name, perm in orders:
