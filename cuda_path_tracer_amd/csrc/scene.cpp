@@ -10,6 +10,7 @@
 #include "scene_host.h"
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -305,13 +306,28 @@ bool HostScene::pack(int n_threads, std::string &err) {
     }
     for (const HostPlane &p : planes)
         if (p.material < 0 || p.material >= (int)materials.size()) { err = "plane references unknown material"; return false; }
-    // kd-trees (meshes one after another; each build uses the whole thread budget)
+    // kd-trees.  The top levels of a build are serial (one thread sorts the root's coordinates, two the next level's,
+    // ...), so several meshes are built side by side, each with its share of the thread budget: 8 x 1.3 M triangles on
+    // 16 threads: 4.5 s one after another with 16 threads each, 1.7 s side by side with 2 each.
     std::vector<KdTree> trees(meshes.size());
     total_tris = total_nodes = total_refs = 0;
+    for (const HostMesh &hm : meshes)
+        if (hm.n_tris <= 0) { err = "empty mesh"; return false; }
+    {
+        const int side_by_side = (int)std::max<size_t>(1, std::min<size_t>(meshes.size(), (size_t)n_threads));
+        const int threads_each = std::max(1, n_threads / side_by_side);
+        std::atomic<size_t> next{0};
+        auto worker = [&]() {
+            for (size_t m = next.fetch_add(1); m < meshes.size(); m = next.fetch_add(1))
+                build_kd_tree(meshes[m].pos.data(), meshes[m].n_tris, trees[m], threads_each);
+        };
+        std::vector<std::thread> pool;
+        for (int w = 1; w < side_by_side; w++) pool.emplace_back(worker);
+        worker();
+        for (std::thread &th : pool) th.join();
+    }
     for (size_t m = 0; m < meshes.size(); m++) {
         HostMesh &hm = meshes[m];
-        if (hm.n_tris <= 0) { err = "empty mesh"; return false; }
-        build_kd_tree(hm.pos.data(), hm.n_tris, trees[m], n_threads);
         hm.tri_base = total_tris;
         hm.node_base = total_nodes;
         hm.ref_base = total_refs;
