@@ -113,6 +113,37 @@ __device__ __forceinline__ Idx3 block_append3(bool pa, bool pb, bool pc, int *ca
     return r;
 }
 
+// Append `cnt` >= 0 entries per thread with one atomic per block; returns the index of the thread's first entry.
+__device__ __forceinline__ int block_append_n(int cnt, int *counter, int *lds, int &phase) {
+    int *slot = lds + phase * (kWaves + 1);
+    phase ^= 1;
+    const int lane = (int)(threadIdx.x & 63u), wave = (int)(threadIdx.x >> 6);
+    int incl = cnt;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int t = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += t;
+    }
+    if (lane == 63) slot[wave] = incl;
+    __syncthreads();
+    if (wave == 0) {
+        const int c = lane < kWaves ? slot[lane] : 0;
+        int wincl = c;
+#pragma unroll
+        for (int off = 1; off < kWaves; off <<= 1) {
+            const int t = __shfl_up(wincl, off, 64);
+            if (lane >= off) wincl += t;
+        }
+        const int total = __shfl(wincl, kWaves - 1, 64);
+        int base = 0;
+        if (lane == 0 && total > 0) base = atomicAdd(counter, total);
+        base = __shfl(base, 0, 64);
+        if (lane < kWaves) slot[lane] = base + wincl - c;
+    }
+    __syncthreads();
+    return slot[wave] + incl - cnt;
+}
+
 __device__ __forceinline__ int wave_sum_i(int v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
@@ -524,13 +555,25 @@ __global__ __launch_bounds__(kBlock) void k_shade(DScene sc, PassParams pp, WfBu
             }
             if (idx < n) b.sh_mask[j] = mask;
         }
-        for (int k = 1; k < pp.K; k++) {  // connection rays: one append per slot kind keeps waves converged
-            const bool emit = (mask >> k) & 1u;
-            const size_t si = emit ? (size_t)j * pp.K + k : 0;
-            const f3 so = emit ? xyz(b.sh_o[si]) : nro, sd = emit ? xyz(b.sh_d[si]) : nrd;
-            if (emit_ray(sc, emit, so, sd, emit ? &b.sh_hit[si] : nullptr, (int)si, b.q_shadow,
-                         &b.counts[kCntPad * (kCntShadow + i)], ap_lds, phase, b.q_shadow_key, kKeyLast))
-                n_trivial++;
+        if (pp.K > 1) {  // connection rays to the light vertices: sphere / plane answers, then ONE append for all of them
+            uint32_t queued = 0u;
+            for (int k = 1; k < pp.K; k++) {
+                if (!((mask >> k) & 1u)) continue;
+                const size_t si = (size_t)j * pp.K + k;
+                const f3 so = xyz(b.sh_o[si]), sd = xyz(b.sh_d[si]);
+                HitRec h;
+                quadrics_closest(sc, so, sd, h.t, h.prim);
+                b.sh_hit[si] = h;
+                if (misses_every_mesh(sc, so, sd)) n_trivial++;
+                else queued |= 1u << k;
+            }
+            int at = block_append_n(__popc(queued), &b.counts[kCntPad * (kCntShadow + i)], ap_lds, phase);
+            for (int k = 1; k < pp.K; k++) {
+                if (!((queued >> k) & 1u)) continue;
+                b.q_shadow[at] = (int)((size_t)j * pp.K + k);
+                if (b.q_shadow_key) b.q_shadow_key[at] = kKeyLast;
+                at++;
+            }
         }
     }
     n_trivial = wave_sum_i(n_trivial);
