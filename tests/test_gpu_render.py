@@ -223,3 +223,27 @@ def test_ray_binning_changes_no_result(monkeypatch):
         assert np.array_equal(a.view(np.uint32), ref.view(np.uint32))
         for k in ("rays_total", "rays_shadow", "rays_camera", "rays_light", "rays_extended", "samples"):
             assert sa[k] == sb[k], k
+
+
+def test_bench_workload_invariants_at_full_resolution(monkeypatch):
+    """C2 as bench.py runs it (1920x1080, icosphere L6, simple depth 6), too large for the oracle: size-independent
+    properties instead.  The image does not depend on how the samples are split into wavefront passes, on ray binning,
+    or on which half of the samples a rank renders (sample interleave sums to the whole up to fp32 addition order)."""
+    desc = G.scene_icosphere_room(6)
+    s = desc.apply(Scene())
+    s.commit(devices=(0,))
+    W, H, SPP = 1920, 1080, 4
+    full, st = s.render(make_config(W, H, spp=SPP, cam_depth=6))
+    assert np.isfinite(full).all() and full.mean() > 0.5
+    assert st["samples"] == W * H * SPP and st["rays_extended"] < st["rays_total"]
+    one_per_pass, _ = s.render(make_config(W, H, spp=SPP, cam_depth=6, samples_per_pass=1))
+    assert np.array_equal(full.view(np.uint32), one_per_pass.view(np.uint32))
+    halves = [s.render(make_config(W, H, spp=SPP, cam_depth=6, sample_begin=g, sample_end=SPP, sample_stride=2))[0] for g in range(2)]
+    assert np.allclose(halves[0] + halves[1], full, rtol=1e-5, atol=1e-6)
+    monkeypatch.setenv("MIPT_SHADOW_SORT", "-1")
+    plain = desc.apply(Scene())
+    plain.commit(devices=(0,))
+    monkeypatch.delenv("MIPT_SHADOW_SORT")
+    unbinned, st2 = plain.render(make_config(W, H, spp=SPP, cam_depth=6))
+    assert np.array_equal(full.view(np.uint32), unbinned.view(np.uint32))
+    assert st2["rays_total"] == st["rays_total"] and st2["rays_extended"] == st["rays_extended"]
