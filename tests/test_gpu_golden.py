@@ -113,3 +113,29 @@ def test_full_size_1m_triangle_mesh_on_ray_subset():
     d = rd[tri] / (np.linalg.norm(rd[tri], axis=1, keepdims=True) + 1e-5)
     r = np.linalg.norm(ro[tri] + d * t[tri, None], axis=1)
     assert np.abs(r - 2.5).max() < 2e-3
+
+
+def test_full_size_10m_triangle_multi_mesh(monkeypatch):
+    # BASELINE config C5's scene: 8 overlapping 1,310,720-triangle icospheres (10,485,760 triangles).  Too large for the
+    # oracle inside a test: the production kernel (mesh ordering, distance pruning with its repeat path, cull boxes,
+    # candidate spheres) is held against the counting kernel, which walks every mesh in the reference's order node for
+    # node and is itself checked against the oracle at the smaller sizes; renders are held against their unbinned twins.
+    desc = G.scene_multi_sphere(8)
+    s = _gpu(desc)
+    assert s.device_bytes() > 2.5e9
+    ro, rd = G.incoherent_rays(1 << 18, (-4.6,) * 3, (4.6,) * 3)
+    co, cd = G.camera_rays(desc.camera, 512, 512, 1 << 18)
+    ro, rd = np.concatenate([ro, co]), np.concatenate([rd, cd])
+    prim, t, st = s.trace_closest(ro, rd, counters=True)
+    fprim, ft, _ = s.trace_closest(ro, rd)
+    assert np.array_equal(fprim, prim) and np.array_equal(ft.view(np.uint32), t.view(np.uint32))
+    tri = (prim >= 0) & (prim < 8 * 1310720)
+    assert tri.mean() > 0.5 and len(np.unique(prim[tri] // 1310720)) == 8  # every mesh is hit by some ray
+    cfgs = (make_config(256, 192, spp=2, cam_depth=5, light_depth=0), make_config(160, 120, spp=2, cam_depth=5, light_depth=5))
+    imgs = [s.render(c)[0] for c in cfgs]
+    monkeypatch.setenv("MIPT_SHADOW_SORT", "-1")
+    plain = _gpu(desc)
+    monkeypatch.delenv("MIPT_SHADOW_SORT")
+    for c, img in zip(cfgs, imgs):
+        assert np.isfinite(img).all() and img.max() > 0.01
+        assert np.array_equal(plain.render(c)[0].view(np.uint32), img.view(np.uint32))
