@@ -139,3 +139,14 @@ def test_full_size_10m_triangle_multi_mesh(monkeypatch):
     for c, img in zip(cfgs, imgs):
         assert np.isfinite(img).all() and img.max() > 0.01
         assert np.array_equal(plain.render(c)[0].view(np.uint32), img.view(np.uint32))
+
+
+@pytest.mark.parametrize("key", ["simple_d6_200spp", "bidir_3_3_200spp"])
+def test_readme_configurations_against_the_reference_renders(key, cube_obj):
+    # the README's own configurations (1024x1024, 200 samples; BASELINE config C3 is the bidirectional one) through the
+    # HIP path, held against the block statistics of the reference's published renders (see tests/readme_util.py)
+    from tests.readme_util import CONFIGS, compare
+    img, st = _gpu(G.scene_default(cube_obj)).render(make_config(1024, 1024, spp=200, **CONFIGS[key]))
+    corr, rel_rms, mean_dev = compare(key, img, 1024, 1024)
+    assert st["samples"] == 1024 * 1024 * 200
+    assert corr > 0.995 and rel_rms < 0.05 and mean_dev < 0.04, (corr, rel_rms, mean_dev)  # measured 0.998/0.026/0.026, 0.996/0.037/0.023
