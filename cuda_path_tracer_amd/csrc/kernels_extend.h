@@ -46,6 +46,8 @@ __device__ __forceinline__ void flush_counters(const TravCounters &tc, unsigned 
 // hits: on entry the sphere / plane answer of every ray (quadrics_closest, written by the stage that made the ray),
 //       on exit the closest hit of the scene.
 // queue: optional indirection (slot ids); count_ptr: optional device-side ray count; work: zeroed counter.
+// tune.common_origin != 0: every ray of the launch starts at the eye (1: primary rays) or at lights[0] (2: direct-
+// connection shadow rays); ray_o is not read -- the stage that made the rays does not write 16 bytes per ray either.
 template <bool COUNT>
 __global__ __launch_bounds__(kExtendBlock, 5) void k_extend(DScene sc, const f4 *__restrict__ ray_o,
                                                          const f4 *__restrict__ ray_d, const int *__restrict__ queue,
@@ -134,8 +136,16 @@ __global__ __launch_bounds__(kExtendBlock, 5) void k_extend(DScene sc, const f4 
                 if (!has_ray && base + rank < n) {
                     PSTAT(ps, 2);
                     slot = (uint32_t)(queue ? queue[base + rank] : base + rank);
-                    const f4 o4 = ray_o[slot], d4 = ray_d[slot];
-                    o = mk3(o4.x, o4.y, o4.z);
+                    const f4 d4 = ray_d[slot];
+                    if (tune.common_origin == 0) {  // wave-uniform
+                        const f4 o4 = ray_o[slot];
+                        o = mk3(o4.x, o4.y, o4.z);
+                    } else if (tune.common_origin == 1) {
+                        o = mk3(sc.cam_eye[0], sc.cam_eye[1], sc.cam_eye[2]);
+                    } else {
+                        const f4 l0 = sc.lights[0];
+                        o = mk3(l0.x, l0.y, l0.z);
+                    }
                     d = mk3(d4.x, d4.y, d4.z);
                     best = -1.0f;
                     prim = -1;
@@ -331,8 +341,10 @@ static __global__ __launch_bounds__(256) void k_split_hits(const HitRec *__restr
 
 // Launch the extend stage on dc.stream.  `work` must point at a zeroed int (the persistent kernel's ray cursor).
 inline void launch_extend(const DeviceCtx &dc, bool count, const f4 *ro, const f4 *rd, const int *queue, const int *count_ptr,
-                          int n_fixed, int64_t n_max, HitRec *hits, int *work, unsigned long long *ctr, bool coherent_queue = false) {
-    const ExtendTuning tune = coherent_queue ? dc.tune_coherent : dc.tune;
+                          int n_fixed, int64_t n_max, HitRec *hits, int *work, unsigned long long *ctr, bool coherent_queue = false,
+                          int common_origin = 0) {  // (common_origin != 0: persistent kernel only)
+    ExtendTuning tune = coherent_queue ? dc.tune_coherent : dc.tune;
+    tune.common_origin = common_origin;
     if (dc.extend_simple) {
         const int64_t want = (n_max + kExtendBlock - 1) / kExtendBlock;
         const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(want, (int64_t)dc.num_cus * 8));

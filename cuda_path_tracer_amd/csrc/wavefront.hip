@@ -205,6 +205,8 @@ struct PassParams {
     int use_env;
     uint32_t seed;
     int tiles_x;         // > 0: paths of a sample are laid out in 8x8 pixel tiles (W and H multiples of 8), else row-major
+    int common_origins;  // simple integrator, persistent extend kernel: primary rays and direct-connection rays are launched
+                         // with their common origin (eye / lights[0]); vertex 0 has no stored origin, throughput or draw count
 };
 
 // Position of a path inside its sample slot <-> pixel.  64 consecutive paths (one wave of primary rays, and what the
@@ -277,9 +279,11 @@ __global__ __launch_bounds__(kBlock) void k_raygen(DScene sc, PassParams pp, WfB
         const float jx = rng.u();  // Q18: first draw -> X, second -> Y
         const float jy = rng.u();
         dir = norm3(camera_dir(sc, (float)col + jx, (float)row + jy, pp.W, pp.H));
-        b.st_o[0][pid] = mk4(ld3(sc.cam_eye), as_f32(rng.draw));  // vertex 0: dense index == path id
+        if (!pp.common_origins) {
+            b.st_o[0][pid] = mk4(ld3(sc.cam_eye), as_f32(rng.draw));  // vertex 0: dense index == path id
+            b.st_T[0][pid] = f4{1.f, 1.f, 1.f, 1.f};
+        }
         b.st_d[0][pid] = mk4(dir, as_f32((uint32_t)pid));
-        b.st_T[0][pid] = f4{1.f, 1.f, 1.f, 1.f};
         b.path_rad[pid] = f4{0.f, 0.f, 0.f, 0.f};
         if (pp.Dl != 0) {
             b.path_rng[pid] = rng.draw;
@@ -424,10 +428,11 @@ __global__ __launch_bounds__(kBlock) void k_shade(DScene sc, PassParams pp, WfBu
         if (idx < n) {
             j = by_id ? b.q_cam0[idx] : idx;
             const HitRec h = b.st_hit[par][j];
-            const f4 o4 = b.st_o[par][j], d4 = b.st_d[par][j];
+            const bool v0 = (i == 0) && pp.common_origins;  // vertex 0 of the simple integrator: eye, throughput 1, two draws made
+            const f4 o4 = v0 ? mk4(ld3(sc.cam_eye), as_f32(2u)) : b.st_o[par][j], d4 = b.st_d[par][j];
             const f3 o = xyz(o4), d = xyz(d4);
             pid = (int)as_u32(d4.w);
-            const f4 Tp = b.st_T[par][j];
+            const f4 Tp = v0 ? f4{1.f, 1.f, 1.f, 1.f} : b.st_T[par][j];
             Tc = xyz(Tp);
             pc = Tp.w;
             if (h.prim < 0) {
@@ -539,7 +544,7 @@ __global__ __launch_bounds__(kBlock) void k_shade(DScene sc, PassParams pp, WfBu
             if (need_extend) {
                 b.q_shadow[qi] = (int)si;
                 if (b.q_shadow_key) b.q_shadow_key[qi] = direction_cell(dr_d);
-                b.sh_o[si] = mk4(lp, 0.f);
+                if (!pp.common_origins) b.sh_o[si] = mk4(lp, 0.f);
                 b.sh_d[si] = mk4(dr_d, 0.f);
                 b.sh_target[si] = mk4(dr_target, 0.f);
                 b.sh_contrib[si] = mk4(dr_contrib, as_f32((uint32_t)pid));
@@ -776,11 +781,12 @@ int wavefront_render(const HostScene &hs, DeviceCtx &dc, const mipt_render_confi
         return e;
     };
     int n_launch = 0;
-    auto extend = [&](const f4 *ro, const f4 *rd, const int *queue, const int *count, HitRec *hits, size_t n_max, bool coherent_queue) {
+    auto extend = [&](const f4 *ro, const f4 *rd, const int *queue, const int *count, HitRec *hits, size_t n_max, bool coherent_queue,
+                      int common_origin = 0) {
         hipEvent_t a = dc.events.next(), e = dc.events.next();
         (void)hipEventRecord(a, sm);
         launch_extend(dc, count_mode, ro, rd, queue, count, 0, (int64_t)n_max, hits, &b.counts[kCntPad * (kCntWork + (n_launch++))],
-                      dc.counters.as<unsigned long long>(), coherent_queue);
+                      dc.counters.as<unsigned long long>(), coherent_queue, common_origin);
         (void)hipEventRecord(e, sm);
         ext_ev.emplace_back(a, e);
     };
@@ -791,6 +797,8 @@ int wavefront_render(const HostScene &hs, DeviceCtx &dc, const mipt_render_confi
     pp.W = cfg.width; pp.H = cfg.height; pp.npix = npix; pp.spp = cfg.spp; pp.sample_stride = stride;
     pp.Dc = Dc; pp.Dl = Dl; pp.K = K; pp.use_env = cfg.use_envmap ? 1 : 0; pp.seed = cfg.seed;
     pp.tiles_x = (cfg.width % 8 == 0 && cfg.height % 8 == 0) ? cfg.width / 8 : 0;
+    pp.common_origins = (K == 1 && !dc.extend_simple) ? 1 : 0;
+
     for (int64_t done = 0; done < n_samples; done += S) {
         pp.n_slots = (int)std::min<int64_t>(S, n_samples - done);
         pp.sample0 = cfg.sample_begin + (int)done * stride;
@@ -813,13 +821,15 @@ int wavefront_render(const HostScene &hs, DeviceCtx &dc, const mipt_render_confi
             }
         }
         for (int i = 0; i < Dc; i++) {
-            extend(b.st_o[i & 1], b.st_d[i & 1], b.q_ext_cam, &b.counts[kCntPad * (kCntExtCam + i)], b.st_hit[i & 1], np, i == 0);
+            extend((i == 0 && pp.common_origins) ? nullptr : b.st_o[i & 1], b.st_d[i & 1], b.q_ext_cam,
+                   &b.counts[kCntPad * (kCntExtCam + i)], b.st_hit[i & 1], np, i == 0, (i == 0 && pp.common_origins) ? 1 : 0);
             hipLaunchKernelGGL(k_shade, dim3(path_grid), dim3(kBlock), 0, sm, dc.view, pp, b, i);
             const int *shadow_queue = b.q_shadow;
             if (sort_shadow && i >= dc.shadow_sort_from)
                 WF_TRY(sort_queue(b.q_shadow_key, b.q_shadow, kCntShadow + i, kShadowKeyBits, shadow_queue));
-            extend(b.sh_o, b.sh_d, shadow_queue, &b.counts[kCntPad * (kCntShadow + i)], b.sh_hit, np * K,
-                   K == 1 && (i == 0 || shadow_queue != b.q_shadow));  // (K > 1: mostly connection rays, in path order)
+            extend(pp.common_origins ? nullptr : b.sh_o, b.sh_d, shadow_queue, &b.counts[kCntPad * (kCntShadow + i)], b.sh_hit, np * K,
+                   K == 1 && (i == 0 || shadow_queue != b.q_shadow),  // (K > 1: mostly connection rays, in path order)
+                   pp.common_origins ? 2 : 0);
             hipLaunchKernelGGL(k_resolve, dim3(path_grid), dim3(kBlock), 0, sm, dc.view, pp, b, i);
             // the shadow queue is refilled from slot 0 by the next vertex: its count lives in its own slot
         }
