@@ -558,7 +558,7 @@ __global__ __launch_bounds__(kBlock) void k_shade(DScene sc, PassParams pp, WfBu
                     b.path_rad[pid] = r;
                 }
             }
-            if (idx < n) b.sh_mask[j] = mask;
+            if (idx < n && pp.K > 1) b.sh_mask[j] = mask;  // (K == 1: k_resolve_queue walks the queue instead)
         }
         if (pp.K > 1) {  // connection rays to the light vertices: sphere / plane answers, then ONE append for all of them
             uint32_t queued = 0u;
@@ -622,6 +622,26 @@ __global__ __launch_bounds__(kBlock) void k_resolve(DScene sc, PassParams pp, Wf
             }
         }
         if (pid >= 0) b.path_rad[pid] = r;
+    }
+}
+
+// The same for the simple integrator (one shadow ray per path and vertex, so no order of additions to keep): walk the
+// shadow QUEUE instead of every alive path -- no per-path mask to write and read, no thread for the 45 % of the paths
+// whose connection was answered on the spot.
+__global__ __launch_bounds__(kBlock) void k_resolve_queue(DScene sc, WfBuffers b, int i) {
+    const int n = b.counts[kCntPad * (kCntShadow + i)];
+    const f3 lp = xyz(sc.lights[0]);
+    for (int idx = blockIdx.x * kBlock + threadIdx.x; idx < n; idx += gridDim.x * kBlock) {
+        const int si = b.q_shadow[idx];
+        const HitRec h = b.sh_hit[si];
+        const f4 tg = b.sh_target[si];
+        if (shadow_visible(lp, norm3(norm3(xyz(tg) - lp)), h.t, tg)) {
+            const f4 c = b.sh_contrib[si];
+            const int pid = (int)as_u32(c.w);
+            f4 r = b.path_rad[pid];
+            r.x = r.x + c.x; r.y = r.y + c.y; r.z = r.z + c.z;
+            b.path_rad[pid] = r;
+        }
     }
 }
 
@@ -830,7 +850,8 @@ int wavefront_render(const HostScene &hs, DeviceCtx &dc, const mipt_render_confi
             extend(pp.common_origins ? nullptr : b.sh_o, b.sh_d, shadow_queue, &b.counts[kCntPad * (kCntShadow + i)], b.sh_hit, np * K,
                    K == 1 && (i == 0 || shadow_queue != b.q_shadow),  // (K > 1: mostly connection rays, in path order)
                    pp.common_origins ? 2 : 0);
-            hipLaunchKernelGGL(k_resolve, dim3(path_grid), dim3(kBlock), 0, sm, dc.view, pp, b, i);
+            if (K == 1) hipLaunchKernelGGL(k_resolve_queue, dim3(path_grid), dim3(kBlock), 0, sm, dc.view, b, i);
+            else hipLaunchKernelGGL(k_resolve, dim3(path_grid), dim3(kBlock), 0, sm, dc.view, pp, b, i);
             // the shadow queue is refilled from slot 0 by the next vertex: its count lives in its own slot
         }
         hipLaunchKernelGGL(k_accumulate, dim3((unsigned)((npix + kBlock - 1) / kBlock)), dim3(kBlock), 0, sm, pp, b, d_accum);
