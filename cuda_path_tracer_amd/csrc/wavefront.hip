@@ -12,14 +12,18 @@
 //   extend                    closest hit of the camera rays                             kernel.cu:240
 //   shade(i)                  direct-light + light-vertex connections emitted as batched shadow rays,
 //                             BSDF sampling / roulette, next ray, queue compaction        kernel.cu:244-302
+//   [sort]                    shadow queue of vertex >= 1 (and the first light rays) ordered by direction: they
+//                             share an origin, so binned they are as coherent as primary rays (rocPRIM radix sort)
 //   extend                    closest hit of the shadow-ray batch (all rays are closest-hit, Q10)
 //   resolve                   visibility compare + in-order accumulation of contributions kernel.cu:249-256,268-279
+//                             (connections answered without the extend kernel are resolved by shade itself)
 //   accumulate                image[id] += trace/nSamples, in sample order               kernel.cu:339-343
 //
-// Queues between stages are built with ballot + mbcnt prefix ranks and ONE atomic per wave; ray counts
-// stay on the device (every extend reads its count from memory), so a pass issues no host sync.
-// Every path's contributions are summed by one lane in the reference's order, so for the simple
-// integrator the image is bit-identical to the CPU oracle's.
+// Queues between stages are built with ballot + mbcnt prefix ranks, an LDS scan over the block's waves and ONE atomic
+// per block and queue; ray counts stay on the device (every extend reads its count from memory) -- the only host round
+// trip inside a pass is the queue length a sort needs.
+// Every path's contributions are summed in the reference's order, and the order of a queue changes no result, so the
+// images are bit-identical to the CPU oracle's.
 #include "wavefront.h"
 
 #include <hip/hip_runtime.h>
