@@ -24,7 +24,9 @@ class Stats(C.Structure):
         ("samples", C.c_int64), ("extend_launches", C.c_int64), ("rays_extended", C.c_int64),
         ("ms_total", C.c_double), ("ms_extend", C.c_double), ("ms_other", C.c_double),
         ("ctr_nodes", C.c_int64), ("ctr_pops", C.c_int64), ("ctr_refs", C.c_int64), ("ctr_tris", C.c_int64),
-        ("ctr_hits", C.c_int64), ("ctr_culled", C.c_int64),
+        ("ctr_hits", C.c_int64), ("ctr_culled", C.c_int64), ("nonfinite_samples", C.c_int64),
+        ("work_steps", C.c_int64), ("work_pops", C.c_int64), ("work_sphere_pairs", C.c_int64), ("work_planes", C.c_int64),
+        ("work_verts", C.c_int64), ("work_leaves", C.c_int64),
     ]
 
     def as_dict(self):
@@ -32,6 +34,8 @@ class Stats(C.Structure):
 
 
 FLAG_COUNTERS = 1
+FLAG_DROP_NONFINITE = 2
+FLAG_WORK_COUNTERS = 4
 
 _F3 = C.POINTER(C.c_float)
 _VP = C.c_void_p
@@ -50,6 +54,10 @@ SIGNATURES = {
     "mipt_scene_set_envmap_rgbe_dir": (C.c_int, [_VP, C.c_char_p]),
     "mipt_scene_set_envmap_f32": (C.c_int, [_VP, _VP, C.c_int, C.c_int]),
     "mipt_scene_commit": (C.c_int, [_VP, C.POINTER(C.c_int), C.c_int]),
+    "mipt_scene_export_size": (C.c_int64, [_VP]),
+    "mipt_scene_export": (C.c_int, [_VP, _VP, C.c_int64]),
+    "mipt_scene_import": (C.c_int, [_VP, _VP, C.c_int64]),
+    "mipt_scene_set_caller_stream": (C.c_int, [_VP, C.c_int, _VP]),
     "mipt_render": (C.c_int, [_VP, C.POINTER(RenderConfig), _VP, C.POINTER(Stats)]),
     "mipt_render_device": (C.c_int, [_VP, C.c_int, C.POINTER(RenderConfig), _VP, C.POINTER(Stats)]),
     "mipt_trace_closest": (C.c_int, [_VP, _VP, _VP, C.c_int64, _VP, _VP, C.POINTER(Stats), C.c_int]),

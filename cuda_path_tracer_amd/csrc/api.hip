@@ -2,6 +2,8 @@
 #include "../../include/mipt.h"
 
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>  // types and prototypes only: librccl is opened at run time, when several devices render one frame
+#include <dlfcn.h>
 
 #include <algorithm>
 #include <chrono>
@@ -23,6 +25,7 @@ struct mipt_scene {
     HostScene host;
     std::vector<DeviceCtx> devs;
     bool committed = false;
+    std::vector<ncclComm_t> comms;  // one per device slot, made by the first mipt_render over several devices
 };
 
 namespace {
@@ -39,18 +42,102 @@ int fail(int code, const std::string &msg) {
             return fail(-2, std::string(#expr) + ": " + hipGetErrorString(e_));                         \
     } while (0)
 
+// RCCL, bound at run time (a process that already holds an RCCL -- PyTorch's -- gets that one; a single-device user never
+// loads it).  Replaces nothing in the reference (single GPU); it is what north_star's "RCCL all-reduce over xGMI" asks for
+// when ONE process drives several devices: each device reduces its partial framebuffer to slot 0 over xGMI.
+struct Rccl {
+    void *lib = nullptr;
+    decltype(&ncclCommInitAll) comm_init_all = nullptr;
+    decltype(&ncclCommDestroy) comm_destroy = nullptr;
+    decltype(&ncclReduce) reduce = nullptr;
+    decltype(&ncclGroupStart) group_start = nullptr;
+    decltype(&ncclGroupEnd) group_end = nullptr;
+    decltype(&ncclGetErrorString) error_string = nullptr;
+    bool load(std::string &err) {
+        if (lib) return true;
+        for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+            lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+            if (lib) break;
+        }
+        if (!lib) { err = std::string("cannot load librccl: ") + dlerror(); return false; }
+        comm_init_all = reinterpret_cast<decltype(comm_init_all)>(dlsym(lib, "ncclCommInitAll"));
+        comm_destroy = reinterpret_cast<decltype(comm_destroy)>(dlsym(lib, "ncclCommDestroy"));
+        reduce = reinterpret_cast<decltype(reduce)>(dlsym(lib, "ncclReduce"));
+        group_start = reinterpret_cast<decltype(group_start)>(dlsym(lib, "ncclGroupStart"));
+        group_end = reinterpret_cast<decltype(group_end)>(dlsym(lib, "ncclGroupEnd"));
+        error_string = reinterpret_cast<decltype(error_string)>(dlsym(lib, "ncclGetErrorString"));
+        if (!comm_init_all || !comm_destroy || !reduce || !group_start || !group_end || !error_string) {
+            err = "librccl lacks an expected symbol";
+            lib = nullptr;
+            return false;
+        }
+        return true;
+    }
+};
+Rccl g_rccl;
+
+void release_comms(mipt_scene *s) {
+    for (ncclComm_t c : s->comms)
+        if (c && g_rccl.comm_destroy) (void)g_rccl.comm_destroy(c);
+    s->comms.clear();
+}
+
+// dst += src over n floats (partial framebuffers of two slots that live on the SAME device: no transport needed)
+__global__ __launch_bounds__(256) void k_add_into(float *__restrict__ dst, const float *__restrict__ src, size_t n) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) dst[i] = dst[i] + src[i];
+}
+
 void release_device(DeviceCtx &dc) {
     if (dc.device < 0) return;
     (void)hipSetDevice(dc.device);
     if (dc.stream) (void)hipStreamSynchronize(dc.stream);
     dc.ray_o.release(); dc.ray_d.release(); dc.hits.release();
-    dc.io_a.release(); dc.io_b.release(); dc.io_c.release(); dc.io_d.release(); dc.counters.release();
+    dc.io_a.release(); dc.io_b.release(); dc.io_c.release(); dc.io_d.release(); dc.counters.release(); dc.accum.release();
     for (DevBuf &b : dc.wf) b.release();
     dc.events.destroy();
+    if (dc.ev_entry) (void)hipEventDestroy(dc.ev_entry);
     if (dc.arena) (void)hipFree(dc.arena);
     if (dc.stream) (void)hipStreamDestroy(dc.stream);
     dc = DeviceCtx();
 }
+
+// The scheduling knobs come from the environment (developer sweeps): a step cap of 0 would leave lanes on interior nodes
+// that never advance, and the persistent kernel would never drain -- clamp everything into its working range.
+void clamp_tuning(ExtendTuning &t) {
+    t.refill_lanes = std::min(64, std::max(1, t.refill_lanes));
+    t.leaf_batch_lanes = std::min(64, std::max(1, t.leaf_batch_lanes));
+    t.step_cap = std::min(64, std::max(1, t.step_cap));
+}
+
+int setup_device(mipt_scene *s, DeviceCtx &dc) {
+    HIP_TRY(hipSetDevice(dc.device));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, dc.device));
+    dc.num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    HIP_TRY(hipStreamCreateWithFlags(&dc.stream, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreateWithFlags(&dc.ev_entry, hipEventDisableTiming));
+    HIP_TRY(hipMalloc(&dc.arena, s->host.arena.size()));
+    HIP_TRY(hipMemcpyAsync(dc.arena, s->host.arena.data(), s->host.arena.size(), hipMemcpyHostToDevice, dc.stream));
+    HIP_TRY(hipStreamSynchronize(dc.stream));
+    HIP_TRY(dc.counters.reserve(kCounterBytes));
+    HIP_TRY(hipMemset(dc.counters.p, 0, kCounterBytes));
+    dc.extend_blocks_per_cu = query_extend_blocks_per_cu();
+    const char *ev = getenv("MIPT_EXTEND");
+    dc.extend_simple = ev && std::string(ev) == "simple";
+    if (const char *sv = getenv("MIPT_SHADOW_SORT")) dc.shadow_sort_from = atoi(sv);
+    if (const char *hv = getenv("MIPT_HEADS")) dc.n_heads = atoi(hv) == 1 ? 1 : 8;
+    if (const char *tv = getenv("MIPT_TUNE")) sscanf(tv, "%d,%d,%d", &dc.tune.refill_lanes, &dc.tune.leaf_batch_lanes, &dc.tune.step_cap);
+    if (const char *tv = getenv("MIPT_TUNE_COHERENT"))
+        sscanf(tv, "%d,%d,%d", &dc.tune_coherent.refill_lanes, &dc.tune_coherent.leaf_batch_lanes, &dc.tune_coherent.step_cap);
+    clamp_tuning(dc.tune);
+    clamp_tuning(dc.tune_coherent);
+    dc.view = s->host.view(dc.arena);
+    return 0;
+}
+
+bool read_only(const mipt_scene *s) { return s->host.imported; }
+const char *kReadOnly = "an imported scene cannot be edited (only its camera): build it from its description instead";
 
 bool check_material(const mipt_scene *s, int m) { return m >= 0 && m < (int)s->host.materials.size(); }
 
@@ -59,6 +146,13 @@ void fill_counters(DeviceCtx &dc, mipt_stats *st) {
     (void)hipMemcpy(c, dc.counters.p, sizeof(c), hipMemcpyDeviceToHost);
     st->ctr_nodes = (int64_t)c[0]; st->ctr_pops = (int64_t)c[1]; st->ctr_refs = (int64_t)c[2];
     st->ctr_tris = (int64_t)c[3]; st->ctr_hits = (int64_t)c[4]; st->ctr_culled = (int64_t)c[5];
+}
+
+// Order the slot's private stream after everything queued so far on the caller's stream (see mipt_scene_set_caller_stream).
+hipError_t wait_for_caller(DeviceCtx &dc) {
+    hipError_t e = hipEventRecord(dc.ev_entry, dc.caller_stream);
+    if (e == hipSuccess) e = hipStreamWaitEvent(dc.stream, dc.ev_entry, 0);
+    return e;
 }
 }  // namespace
 
@@ -79,6 +173,7 @@ int mipt_scene_create(mipt_scene **out) {
 
 void mipt_scene_destroy(mipt_scene *s) {
     if (!s) return;
+    release_comms(s);
     for (DeviceCtx &dc : s->devs) release_device(dc);
     delete s;
 }
@@ -93,6 +188,7 @@ int mipt_scene_set_camera(mipt_scene *s, const float eye[3], const float lookat[
 
 int mipt_scene_add_material(mipt_scene *s, const float kd[3], const float ks[3]) {
     if (!s) return fail(-1, "null scene");
+    if (read_only(s)) return fail(-1, kReadOnly);
     HostMaterial m;
     for (int k = 0; k < 3; k++) { m.kd[k] = kd[k]; m.ks[k] = ks[k]; }
     s->host.materials.push_back(m);
@@ -102,6 +198,7 @@ int mipt_scene_add_material(mipt_scene *s, const float kd[3], const float ks[3])
 
 int mipt_scene_add_light(mipt_scene *s, const float loc[3], const float power[3]) {
     if (!s) return fail(-1, "null scene");
+    if (read_only(s)) return fail(-1, kReadOnly);
     HostLight l;
     for (int k = 0; k < 3; k++) { l.loc[k] = loc[k]; l.power[k] = power[k]; }
     s->host.lights.push_back(l);
@@ -111,6 +208,7 @@ int mipt_scene_add_light(mipt_scene *s, const float loc[3], const float power[3]
 
 int mipt_scene_add_plane(mipt_scene *s, const float point[3], const float normal[3], int material) {
     if (!s) return fail(-1, "null scene");
+    if (read_only(s)) return fail(-1, kReadOnly);
     if (!check_material(s, material)) return fail(-1, "unknown material id");
     HostPlane p;
     const f3 n = norm3(mk3(normal[0], normal[1], normal[2]));  // Plane ctor normalises (plane.cuh:16)
@@ -124,6 +222,7 @@ int mipt_scene_add_plane(mipt_scene *s, const float point[3], const float normal
 
 int mipt_scene_add_sphere(mipt_scene *s, const float center[3], float radius, int material) {
     if (!s) return fail(-1, "null scene");
+    if (read_only(s)) return fail(-1, kReadOnly);
     if (!check_material(s, material)) return fail(-1, "unknown material id");
     HostSphere sp;
     for (int k = 0; k < 3; k++) sp.center[k] = center[k];
@@ -136,6 +235,7 @@ int mipt_scene_add_sphere(mipt_scene *s, const float center[3], float radius, in
 
 int mipt_scene_add_mesh(mipt_scene *s, const float *pos, const float *nrm, int64_t n_tris, int material) {
     if (!s || !pos || !nrm) return fail(-1, "null argument");
+    if (read_only(s)) return fail(-1, kReadOnly);
     if (n_tris <= 0) return fail(-1, "a mesh needs at least one triangle");
     if (!check_material(s, material)) return fail(-1, "unknown material id");
     HostMesh m;
@@ -151,6 +251,7 @@ int mipt_scene_add_mesh(mipt_scene *s, const float *pos, const float *nrm, int64
 int mipt_scene_add_mesh_obj(mipt_scene *s, const char *path, const float position[3], const float rotate[3],
                             const float scale[3], int material) {
     if (!s || !path) return fail(-1, "null argument");
+    if (read_only(s)) return fail(-1, kReadOnly);
     if (!check_material(s, material)) return fail(-1, "unknown material id");
     HostMesh m;
     std::string err;
@@ -163,6 +264,7 @@ int mipt_scene_add_mesh_obj(mipt_scene *s, const char *path, const float positio
 
 int mipt_scene_set_envmap_rgbe_dir(mipt_scene *s, const char *folder) {
     if (!s || !folder) return fail(-1, "null argument");
+    if (read_only(s)) return fail(-1, kReadOnly);
     static const char *names[6] = {"px.hdr", "py.hdr", "pz.hdr", "nx.hdr", "ny.hdr", "nz.hdr"};  // envMap.cuh:35-40
     HostEnv env;
     for (int f = 0; f < 6; f++) {
@@ -181,6 +283,7 @@ int mipt_scene_set_envmap_rgbe_dir(mipt_scene *s, const char *folder) {
 
 int mipt_scene_set_envmap_f32(mipt_scene *s, const float *faces6, int w, int h) {
     if (!s || !faces6 || w <= 0 || h <= 0) return fail(-1, "bad argument");
+    if (read_only(s)) return fail(-1, kReadOnly);
     HostEnv env;
     env.w = w;
     env.h = h;
@@ -193,35 +296,33 @@ int mipt_scene_set_envmap_f32(mipt_scene *s, const float *faces6, int w, int h) 
 int mipt_scene_commit(mipt_scene *s, const int *device_ids, int n_devices) {
     if (!s) return fail(-1, "null scene");
     if (n_devices < 0 || (n_devices > 0 && !device_ids)) return fail(-1, "bad device list");
+    release_comms(s);
     for (DeviceCtx &dc : s->devs) release_device(dc);
     s->devs.clear();
     s->committed = false;
     std::string err;
-    if (!s->host.pack(0, err)) return fail(-4, err);
+    if (!s->host.imported && !s->host.pack(0, err)) return fail(-4, err);  // an imported scene is already packed
     for (int i = 0; i < n_devices; i++) {
         DeviceCtx dc;
         dc.device = device_ids[i];
-        HIP_TRY(hipSetDevice(dc.device));
-        hipDeviceProp_t prop;
-        HIP_TRY(hipGetDeviceProperties(&prop, dc.device));
-        dc.num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-        HIP_TRY(hipStreamCreateWithFlags(&dc.stream, hipStreamNonBlocking));
-        HIP_TRY(hipMalloc(&dc.arena, s->host.arena.size()));
-        HIP_TRY(hipMemcpyAsync(dc.arena, s->host.arena.data(), s->host.arena.size(), hipMemcpyHostToDevice, dc.stream));
-        HIP_TRY(hipStreamSynchronize(dc.stream));
-        HIP_TRY(dc.counters.reserve(512));
-        HIP_TRY(hipMemset(dc.counters.p, 0, 512));  // [0,64) traversal counters, [64,128) work cursor of the persistent kernel
-        dc.extend_blocks_per_cu = query_extend_blocks_per_cu();
-        const char *ev = getenv("MIPT_EXTEND");
-        dc.extend_simple = ev && std::string(ev) == "simple";
-        if (const char *sv = getenv("MIPT_SHADOW_SORT")) dc.shadow_sort_from = atoi(sv);
-        if (const char *tv = getenv("MIPT_TUNE")) sscanf(tv, "%d,%d,%d", &dc.tune.refill_lanes, &dc.tune.leaf_batch_lanes, &dc.tune.step_cap);
-        if (const char *tv = getenv("MIPT_TUNE_COHERENT"))
-            sscanf(tv, "%d,%d,%d", &dc.tune_coherent.refill_lanes, &dc.tune_coherent.leaf_batch_lanes, &dc.tune_coherent.step_cap);
-        dc.view = s->host.view(dc.arena);
+        const int rc = setup_device(s, dc);
+        if (rc != 0) {  // nothing of a half set-up slot is kept (stream, arena, counters); earlier slots stay usable
+            const std::string why = g_err;
+            release_device(dc);
+            for (DeviceCtx &d : s->devs) release_device(d);
+            s->devs.clear();
+            return fail(rc, why);
+        }
         s->devs.push_back(dc);
     }
     s->committed = true;
+    return 0;
+}
+
+int mipt_scene_set_caller_stream(mipt_scene *s, int slot, void *hip_stream) {
+    if (!s || !s->committed) return fail(-1, "scene not committed");
+    if (slot < 0 || slot >= (int)s->devs.size()) return fail(-1, "scene is not committed on that device slot");
+    s->devs[(size_t)slot].caller_stream = static_cast<hipStream_t>(hip_stream);
     return 0;
 }
 
@@ -241,14 +342,16 @@ int mipt_trace_closest_device(mipt_scene *s, int slot, const float *d_ray_o, con
     dc.events.reset();
     hipEvent_t e0 = dc.events.next(), e1 = dc.events.next(), e2 = dc.events.next(), e3 = dc.events.next();
     const bool count = (flags & MIPT_FLAG_COUNTERS) != 0;
-    HIP_TRY(hipMemsetAsync(dc.counters.p, 0, 512, dc.stream));
+    const int mode = extend_mode(flags);
+    HIP_TRY(wait_for_caller(dc));
+    HIP_TRY(hipMemsetAsync(dc.counters.p, 0, kCounterBytes, dc.stream));
     const int blocks = (int)((n + 255) / 256);
     HIP_TRY(hipEventRecord(e0, dc.stream));
     hipLaunchKernelGGL(k_make_rays, dim3(blocks), dim3(256), 0, dc.stream, dc.view, d_ray_o, d_ray_d, n, dc.ray_o.as<f4>(),
                        dc.ray_d.as<f4>(), dc.hits.as<HitRec>());
     HIP_TRY(hipEventRecord(e1, dc.stream));
-    launch_extend(dc, count, dc.ray_o.as<f4>(), dc.ray_d.as<f4>(), nullptr, nullptr, (int)n, n, dc.hits.as<HitRec>(),
-                  reinterpret_cast<int *>(dc.counters.as<char>() + 64), dc.counters.as<unsigned long long>());
+    launch_extend(dc, mode, dc.ray_o.as<f4>(), dc.ray_d.as<f4>(), nullptr, nullptr, (int)n, n, dc.hits.as<HitRec>(),
+                  reinterpret_cast<int *>(dc.counters.as<char>() + kCtrCursor), dc.counters.as<unsigned long long>());
     HIP_TRY(hipEventRecord(e2, dc.stream));
     hipLaunchKernelGGL(k_split_hits, dim3(blocks), dim3(256), 0, dc.stream, dc.hits.as<HitRec>(), n, d_prim, d_t);
     HIP_TRY(hipEventRecord(e3, dc.stream));
@@ -265,6 +368,7 @@ int mipt_trace_closest_device(mipt_scene *s, int slot, const float *d_ray_o, con
         st->ms_extend = ms_ext;
         st->ms_other = ms_all - ms_ext;
         if (count) fill_counters(dc, st);
+        if (mode == kCountWork) fill_work_counters(dc, st);
     }
 #ifdef MIPT_PHASE_STATS
     if (!count) dump_phase_stats(dc, "trace_closest");
@@ -299,6 +403,8 @@ int mipt_render_device(mipt_scene *s, int slot, const mipt_render_config *cfg, f
     if (!s || !s->committed) return fail(-1, "scene not committed");
     if (slot < 0 || slot >= (int)s->devs.size()) return fail(-1, "scene is not committed on that device slot");
     if (!cfg || !d_accum) return fail(-1, "null argument");
+    HIP_TRY(hipSetDevice(s->devs[slot].device));
+    HIP_TRY(wait_for_caller(s->devs[slot]));
     std::string err;
     int rc = wavefront_render(s->host, s->devs[slot], *cfg, d_accum, st, err);
     if (rc != 0) return fail(rc, err);
@@ -312,29 +418,21 @@ int mipt_render(mipt_scene *s, const mipt_render_config *cfg, float *out, mipt_s
     if (cfg->width <= 0 || cfg->height <= 0) return fail(-1, "bad image size");
     const size_t npix = (size_t)cfg->width * cfg->height;
     const int G = (int)s->devs.size();
-    std::vector<std::vector<float>> partial((size_t)G);
     std::vector<mipt_stats> stats((size_t)G);
     std::vector<int> rcs((size_t)G, 0);
     std::vector<std::string> errs((size_t)G);
+    // every slot renders its samples (s mod G) into its own device framebuffer, kept from call to call
     auto work = [&](int g) {
         DeviceCtx &dc = s->devs[(size_t)g];
         mipt_render_config c = *cfg;
         const int stride = c.sample_stride > 0 ? c.sample_stride : 1;
         c.sample_begin = cfg->sample_begin + g * stride;  // samples s = begin + (g + k*G)*stride
         c.sample_stride = stride * G;
-        if (hipSetDevice(dc.device) != hipSuccess) { rcs[(size_t)g] = -2; errs[(size_t)g] = "hipSetDevice failed"; return; }
-        float *d_acc = nullptr;
-        if (hipMalloc((void **)&d_acc, npix * 12) != hipSuccess) { rcs[(size_t)g] = -2; errs[(size_t)g] = "hipMalloc(accum) failed"; return; }
-        (void)hipMemsetAsync(d_acc, 0, npix * 12, dc.stream);
-        rcs[(size_t)g] = wavefront_render(s->host, dc, c, d_acc, &stats[(size_t)g], errs[(size_t)g]);
-        if (rcs[(size_t)g] == 0) {
-            partial[(size_t)g].resize(npix * 3);
-            if (hipMemcpy(partial[(size_t)g].data(), d_acc, npix * 12, hipMemcpyDeviceToHost) != hipSuccess) {
-                rcs[(size_t)g] = -2;
-                errs[(size_t)g] = "hipMemcpy(accum) failed";
-            }
-        }
-        (void)hipFree(d_acc);
+        hipError_t e = hipSetDevice(dc.device);
+        if (e == hipSuccess) e = dc.accum.reserve(npix * 12);
+        if (e == hipSuccess) e = hipMemsetAsync(dc.accum.p, 0, npix * 12, dc.stream);
+        if (e != hipSuccess) { rcs[(size_t)g] = -2; errs[(size_t)g] = std::string("framebuffer set-up: ") + hipGetErrorString(e); return; }
+        rcs[(size_t)g] = wavefront_render(s->host, dc, c, dc.accum.as<float>(), &stats[(size_t)g], errs[(size_t)g]);
     };
     if (G == 1) work(0);
     else {
@@ -344,19 +442,64 @@ int mipt_render(mipt_scene *s, const mipt_render_config *cfg, float *out, mipt_s
     }
     for (int g = 0; g < G; g++)
         if (rcs[(size_t)g] != 0) return fail(rcs[(size_t)g], errs[(size_t)g]);
-    memcpy(out, partial[0].data(), npix * 12);
-    for (int g = 1; g < G; g++)
-        for (size_t i = 0; i < npix * 3; i++) out[i] += partial[(size_t)g][i];
+    // combine on the devices: ONE RCCL reduce to slot 0 over xGMI (replaces G device-to-host copies and a host sum); slots
+    // that share a physical device (a test set-up) are added by a kernel on that device instead -- RCCL wants distinct ones
+    bool distinct = true;
+    for (int a = 0; a < G; a++)
+        for (int b = a + 1; b < G; b++) distinct &= s->devs[(size_t)a].device != s->devs[(size_t)b].device;
+    const char *force = getenv("MIPT_FORCE_RCCL");
+    if (distinct && (G > 1 || (force && atoi(force) != 0))) {
+        std::string err;
+        if (!g_rccl.load(err)) return fail(-6, err);
+        if (s->comms.empty()) {
+            std::vector<int> ids;
+            for (const DeviceCtx &dc : s->devs) ids.push_back(dc.device);
+            s->comms.assign((size_t)G, nullptr);
+            const ncclResult_t r = g_rccl.comm_init_all(s->comms.data(), G, ids.data());
+            if (r != ncclSuccess) { s->comms.clear(); return fail(-6, std::string("ncclCommInitAll: ") + g_rccl.error_string(r)); }
+        }
+        ncclResult_t r = g_rccl.group_start();
+        for (int g = 0; g < G && r == ncclSuccess; g++) {
+            DeviceCtx &dc = s->devs[(size_t)g];
+            HIP_TRY(hipSetDevice(dc.device));
+            r = g_rccl.reduce(dc.accum.p, dc.accum.p, npix * 3, ncclFloat, ncclSum, 0, s->comms[(size_t)g], dc.stream);
+        }
+        const ncclResult_t r2 = g_rccl.group_end();
+        if (r == ncclSuccess) r = r2;
+        if (r != ncclSuccess) return fail(-6, std::string("ncclReduce: ") + g_rccl.error_string(r));
+        for (int g = G - 1; g >= 0; g--) {
+            HIP_TRY(hipSetDevice(s->devs[(size_t)g].device));
+            HIP_TRY(hipStreamSynchronize(s->devs[(size_t)g].stream));
+        }
+    } else if (G > 1) {
+        DeviceCtx &root = s->devs[0];
+        HIP_TRY(hipSetDevice(root.device));
+        for (int g = 1; g < G; g++) {
+            if (s->devs[(size_t)g].device != root.device)
+                return fail(-1, "device slots must be all distinct (RCCL reduce) or all on one device");
+            hipLaunchKernelGGL(k_add_into, dim3((unsigned)((npix * 3 + 255) / 256)), dim3(256), 0, root.stream, root.accum.as<float>(),
+                               s->devs[(size_t)g].accum.as<float>(), npix * 3);
+        }
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipStreamSynchronize(root.stream));
+    }
+    HIP_TRY(hipSetDevice(s->devs[0].device));
+    HIP_TRY(hipMemcpy(out, s->devs[0].accum.p, npix * 12, hipMemcpyDeviceToHost));  // kernel.cu:416
     if (st) {
         *st = stats[0];
         for (int g = 1; g < G; g++) {
-            st->rays_total += stats[(size_t)g].rays_total; st->rays_camera += stats[(size_t)g].rays_camera;
-            st->rays_shadow += stats[(size_t)g].rays_shadow; st->rays_light += stats[(size_t)g].rays_light;
-            st->samples += stats[(size_t)g].samples; st->extend_launches += stats[(size_t)g].extend_launches;
-            st->rays_extended += stats[(size_t)g].rays_extended;
-            st->ms_total = std::max(st->ms_total, stats[(size_t)g].ms_total);
-            st->ms_extend = std::max(st->ms_extend, stats[(size_t)g].ms_extend);
-            st->ms_other = std::max(st->ms_other, stats[(size_t)g].ms_other);
+            const mipt_stats &o = stats[(size_t)g];
+            st->rays_total += o.rays_total; st->rays_camera += o.rays_camera;
+            st->rays_shadow += o.rays_shadow; st->rays_light += o.rays_light;
+            st->samples += o.samples; st->extend_launches += o.extend_launches;
+            st->rays_extended += o.rays_extended; st->nonfinite_samples += o.nonfinite_samples;
+            st->ctr_nodes += o.ctr_nodes; st->ctr_pops += o.ctr_pops; st->ctr_refs += o.ctr_refs; st->ctr_tris += o.ctr_tris;
+            st->ctr_hits += o.ctr_hits; st->ctr_culled += o.ctr_culled;
+            st->work_steps += o.work_steps; st->work_pops += o.work_pops; st->work_sphere_pairs += o.work_sphere_pairs;
+            st->work_planes += o.work_planes; st->work_verts += o.work_verts; st->work_leaves += o.work_leaves;
+            st->ms_total = std::max(st->ms_total, o.ms_total);
+            st->ms_extend = std::max(st->ms_extend, o.ms_extend);
+            st->ms_other = std::max(st->ms_other, o.ms_other);
         }
     }
     return 0;
@@ -421,8 +564,43 @@ int mipt_mesh_triangles(mipt_scene *s, int mesh, float *pos9, float *nrm9) {
     if (!s) return fail(-1, "null scene");
     if (mesh < 0 || mesh >= (int)s->host.meshes.size()) return fail(-1, "bad mesh index");
     const HostMesh &m = s->host.meshes[(size_t)mesh];
-    if (pos9) memcpy(pos9, m.pos.data(), m.pos.size() * 4);
-    if (nrm9) memcpy(nrm9, m.nrm.data(), m.nrm.size() * 4);
+    if (!s->host.imported) {
+        if (pos9) memcpy(pos9, m.pos.data(), m.pos.size() * 4);
+        if (nrm9) memcpy(nrm9, m.nrm.data(), m.nrm.size() * 4);
+        return 0;
+    }
+    // an imported scene keeps no triangle arrays: read them back from the packed float4 records
+    const DScene v = s->host.view(s->host.arena.data());
+    for (int64_t i = 0; i < m.n_tris * 3; i++) {
+        const f4 p = v.tri_pos[3 * m.tri_base + i], n = v.tri_nrm[3 * m.tri_base + i];
+        if (pos9) { pos9[3 * i] = p.x; pos9[3 * i + 1] = p.y; pos9[3 * i + 2] = p.z; }
+        if (nrm9) { nrm9[3 * i] = n.x; nrm9[3 * i + 1] = n.y; nrm9[3 * i + 2] = n.z; }
+    }
+    return 0;
+}
+
+int64_t mipt_scene_export_size(mipt_scene *s) {
+    if (!s || !s->host.packed) return fail(-1, "scene not committed");
+    return (int64_t)export_blob(s->host, nullptr);
+}
+
+int mipt_scene_export(mipt_scene *s, void *blob, int64_t size) {
+    if (!s || !s->host.packed) return fail(-1, "scene not committed");
+    if (!blob || size < (int64_t)export_blob(s->host, nullptr)) return fail(-1, "export buffer too small");
+    export_blob(s->host, static_cast<uint8_t *>(blob));
+    return 0;
+}
+
+int mipt_scene_import(mipt_scene *s, const void *blob, int64_t size) {
+    if (!s || !blob || size <= 0) return fail(-1, "bad argument");
+    release_comms(s);
+    for (DeviceCtx &dc : s->devs) release_device(dc);
+    s->devs.clear();
+    s->committed = false;
+    std::string err;
+    HostScene fresh;
+    if (!import_blob(fresh, static_cast<const uint8_t *>(blob), (size_t)size, err)) return fail(-5, err);
+    s->host = std::move(fresh);
     return 0;
 }
 

@@ -59,12 +59,22 @@ struct ExtendTuning {
     int leaf_batch_lanes = 28;  // scan leaves once this many lanes wait at one (or fewer lanes than this still traverse)
     int step_cap = 4;           // node steps per lane per round before lanes re-converge
     int common_origin = 0;      // per launch: 0 = rays carry their origins, 1 = all start at the eye, 2 = all start at lights[0]
+    int n_heads = 8;            // ray cursors of the launch (8: one per XCD; 1: a single word, for A/B timing -- MIPT_HEADS)
     // (defaults from the sweeps of scripts/tune.sh on MI355X; the optimum is flat within ~3 % around them)
 };
+
+// Layout of DeviceCtx::counters (bytes): what mipt_trace_closest* uses outside a wavefront pass.
+constexpr size_t kCtrRef = 0;        // 8 x u64: counters of the reference walk (k_extend<kCountRef>)
+constexpr size_t kCtrPhase = 128;    // 24 x u64: developer build, per-phase lane use
+constexpr size_t kCtrWork = 320;     // 8 x u64: what the production kernel read (k_extend<kCountWork>)
+constexpr size_t kCtrCursor = 1024;  // 8 ray cursors of the persistent kernel, 256 B apart (one per XCD)
+constexpr size_t kCounterBytes = kCtrCursor + 8 * 256;
 
 struct DeviceCtx {
     int device = -1;
     hipStream_t stream = nullptr;
+    hipStream_t caller_stream = nullptr;  // mipt_scene_set_caller_stream: what the *_device entry points order themselves after
+    hipEvent_t ev_entry = nullptr;        // recorded on caller_stream at entry, waited for by `stream`
     void *arena = nullptr;
     DScene view;
     int num_cus = 256;
@@ -74,10 +84,12 @@ struct DeviceCtx {
     // together, so refilling only when nearly the whole wave is idle keeps neighbouring rays in one wave: +3.5 % on the
     // 1080p box-room frame over refilling at 32 (40 / 48 / 56 / 60 / 64 idle lanes: 640 / 647 / 652 / 653 / 651 Msamples/s).
     ExtendTuning tune_coherent = {60, 28, 4};
+    int n_heads = 8;               // MIPT_HEADS=1|8: ray cursors per launch of the persistent kernel
     bool extend_simple = false;    // MIPT_EXTEND=simple: grid-stride reference kernel (A/B timing)
     int shadow_sort_from = 1;      // MIPT_SHADOW_SORT=<vertex>: first camera vertex whose shadow rays are binned by direction (-1: never)
     // closest-hit work buffers
     DevBuf ray_o, ray_d, hits, io_a, io_b, io_c, io_d, counters;
+    DevBuf accum;  // mipt_render: this slot's partial framebuffer (W*H*3 fp32), reduced to slot 0 on the devices
     // wavefront work buffers (see wavefront.hip)
     DevBuf wf[36];
     EventPool events;

@@ -8,6 +8,12 @@
 // lane never waits for a neighbour's whole ray, only for its current few steps / leaf scan.
 // The traversal stack is an LDS array laid out [slot][lane]: a wave's 64 lanes hit 64 consecutive banks.
 // The ray count is read from device memory (no host round trip between bounces of the wavefront tracer).
+//
+// Work cursors: ONE word pulled by 5,120 waves saturates (a same-address atomic completes at ~88 M/s on MI355X and the
+// 1080p frame asked for 72 M/s), so the queue is cut into 8 contiguous ranges with a cursor each, 256 B apart; the waves
+// of workgroup b start on range b mod 8 (workgroups go round the 8 XCDs, so one XCD's L2 sees one eighth of a coherent
+// queue instead of all of it) and move on to the next range when theirs runs dry, until all eight are.  Which range a
+// wave pulls from changes no result.
 #pragma once
 #include <hip/hip_runtime.h>
 #include "device_ctx.h"
@@ -29,6 +35,18 @@ __device__ __forceinline__ unsigned int wave_sum(unsigned int v) {
     return v;
 }
 
+// kernel variants: the production walk; the reference's walk node for node with its counters (SURVEY 8d's units); the
+// production walk that also counts what it reads (product-layout algorithmic bytes)
+constexpr int kProd = 0, kCountRef = 1, kCountWork = 2;
+constexpr int kCursorStride = 64;  // ints between two cursors (256 B)
+
+__device__ __forceinline__ void flush_work_counters(const WorkCounters &wc, unsigned long long *ctr) {
+    const unsigned int v[6] = {wave_sum(wc.steps), wave_sum(wc.pops), wave_sum(wc.sphere_pairs), wave_sum(wc.planes),
+                               wave_sum(wc.verts), wave_sum(wc.leaves)};
+    if ((threadIdx.x & 63) == 0)
+        for (int i = 0; i < 6; i++) atomicAdd(&ctr[i], (unsigned long long)v[i]);
+}
+
 __device__ __forceinline__ void flush_counters(const TravCounters &tc, unsigned int hit_tris, unsigned long long *ctr) {
     const unsigned int a = wave_sum(tc.nodes), b = wave_sum(tc.pops), c = wave_sum(tc.refs), d = wave_sum(tc.tris),
                        e = wave_sum(hit_tris), f = wave_sum(tc.culled);
@@ -48,16 +66,24 @@ __device__ __forceinline__ void flush_counters(const TravCounters &tc, unsigned 
 // queue: optional indirection (slot ids); count_ptr: optional device-side ray count; work: zeroed counter.
 // tune.common_origin != 0: every ray of the launch starts at the eye (1: primary rays) or at lights[0] (2: direct-
 // connection shadow rays); ray_o is not read -- the stage that made the rays does not write 16 bytes per ray either.
-template <bool COUNT>
+template <int MODE>
 __global__ __launch_bounds__(kExtendBlock, 5) void k_extend(DScene sc, const f4 *__restrict__ ray_o,
                                                          const f4 *__restrict__ ray_d, const int *__restrict__ queue,
                                                          const int *__restrict__ count_ptr, int n_fixed,
                                                          HitRec *__restrict__ hits, int *__restrict__ work,
                                                          unsigned long long *ctr, ExtendTuning tune) {
+    constexpr bool COUNT = MODE == kCountRef;
+    constexpr bool WORK = MODE == kCountWork;
     __shared__ int stack_mem[kStackDepth * kExtendBlock];
     LdsStack stk{stack_mem + threadIdx.x};
     const int n = count_ptr ? *count_ptr : n_fixed;
     const int lane = (int)(threadIdx.x & 63u);
+    // the 8 ranges of the queue (multiples of 64 rays) and the one this wave pulls from
+    const int n_heads = tune.n_heads;  // 1 or 8
+    const int range = n_heads == 1 ? n : (int)((((long long)n + 7) / 8 + 63) & ~63ll);
+    int head = n_heads == 1 ? 0 : (int)(blockIdx.x & 7u);
+    int heads_dry = 0;
+    WorkCounters wc = {0u, 0u, 0u, 0u, 0u, 0u};
     const int root0 = sc.n_meshes > 0 ? sc.meshes[0].root : 0;  // wave-uniform: one link less in a fresh ray's load chain
     TravCounters tc = {0u, 0u, 0u, 0u, 0u};
     unsigned int hit_tris = 0;
@@ -129,13 +155,16 @@ __global__ __launch_bounds__(kExtendBlock, 5) void k_extend(DScene sc, const f4 
             if (n_idle >= tune.refill_lanes || n_idle == 64) {
                 const int leader = __ffsll((long long)idle) - 1;
                 int base = 0;
-                if (lane == leader) base = atomicAdd(work, n_idle);
+                if (lane == leader) base = atomicAdd(work + head * kCursorStride, n_idle);
                 base = __shfl(base, leader, 64);
+                const long long lo = (long long)range * head;               // wave-uniform
+                const long long hi = lo + range < (long long)n ? lo + range : (long long)n;
                 const int rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned int)(idle >> 32),
                                                                 __builtin_amdgcn_mbcnt_lo((unsigned int)idle, 0u));
-                if (!has_ray && base + rank < n) {
+                if (!has_ray && lo + base + rank < hi) {
                     PSTAT(ps, 2);
-                    slot = (uint32_t)(queue ? queue[base + rank] : base + rank);
+                    const int qi = (int)(lo + base + rank);
+                    slot = (uint32_t)(queue ? queue[qi] : qi);
                     const f4 d4 = ray_d[slot];
                     if (tune.common_origin == 0) {  // wave-uniform
                         const f4 o4 = ray_o[slot];
@@ -160,7 +189,11 @@ __global__ __launch_bounds__(kExtendBlock, 5) void k_extend(DScene sc, const f4 
                     need_pop = false;
                     has_ray = true;
                 }
-                if (base + n_idle >= n) exhausted = true;  // wave-uniform: base and n_idle are
+                if (lo + base + n_idle >= hi) {  // wave-uniform: this range is used up -- on to the next one
+                    heads_dry++;
+                    head = (head + 1) & 7;
+                    if (heads_dry >= n_heads) exhausted = true;
+                }
             }
         }
         if (__ballot(has_ray) == 0ull) {
@@ -202,6 +235,7 @@ __global__ __launch_bounds__(kExtendBlock, 5) void k_extend(DScene sc, const f4 
             } else {
                 mask_slab(cur, o, d);
                 enter = masked_min(cur.tlo, cur.thi) > 0.0f;
+                if (WORK) wc.pops++;
             }
             if (enter) {
                 sp = 0;
@@ -223,7 +257,7 @@ __global__ __launch_bounds__(kExtendBlock, 5) void k_extend(DScene sc, const f4 
                     float bt;
                     int bi;
                     PSTAT(ps, 4);
-                    leaf_scan(sc, (int)nd.a, (int)(nd.b & kIdxMask), o, d, cur, bt, bi PSTAT_PASS);
+                    leaf_scan<WORK>(sc, (int)nd.a, (int)(nd.b & kIdxMask), o, d, cur, bt, bi, wc PSTAT_PASS);
                     pending = false;
                     after_leaf(bt, bi);
                 }
@@ -248,6 +282,7 @@ __global__ __launch_bounds__(kExtendBlock, 5) void k_extend(DScene sc, const f4 
             load_slab(sc, node, o, d, cur);
             mask_slab(cur, o, d);
             need_pop = false;
+            if (WORK) wc.pops++;
             if ((nd.b >> 30) == 3u) pending = true;
         }
         if (!has_ray || pending || start_mesh) continue;
@@ -267,14 +302,15 @@ __global__ __launch_bounds__(kExtendBlock, 5) void k_extend(DScene sc, const f4 
             }
         } else {
             const float t_prune = (prune_meshes && (slot & kNoPruneBit) == 0u) ? closest_so_far() : inf;
-            const bool dead_end = descend_fast<LdsStack>(sc, o, d, cur, node, nd, sp, stk, tune.step_cap, prune_meshes, t_prune, slot, kTaintBit PSTAT_PASS);
+            const bool dead_end = descend_fast<LdsStack, WORK>(sc, o, d, cur, node, nd, sp, stk, tune.step_cap, prune_meshes, t_prune, slot, kTaintBit, wc PSTAT_PASS);
             if (dead_end) after_leaf(-1.0f, -1);                 // same continuation as a fruitless leaf visit
             else if ((nd.b >> 30) == 3u) pending = true;        // a leaf that passed its cull test: scanned in a batch
         }
     }
     if (COUNT) flush_counters(tc, hit_tris, ctr);
+    if (WORK) flush_work_counters(wc, ctr + kCtrWork / 8);
 #ifdef MIPT_PHASE_STATS
-    if (!COUNT) {  // ctr + 16: after the traversal counters and the work cursor (see api.hip)
+    if (!COUNT) {  // ctr + 16: kCtrPhase (device_ctx.h)
         for (int i = 0; i < kPhases; i++) {
             const unsigned int e = wave_sum(ps.exec[i]), l = wave_sum(ps.lanes[i]);
             if (lane == 0) {
@@ -339,12 +375,15 @@ static __global__ __launch_bounds__(256) void k_split_hits(const HitRec *__restr
     t[i] = h.t;
 }
 
-// Launch the extend stage on dc.stream.  `work` must point at a zeroed int (the persistent kernel's ray cursor).
-inline void launch_extend(const DeviceCtx &dc, bool count, const f4 *ro, const f4 *rd, const int *queue, const int *count_ptr,
+// Launch the extend stage on dc.stream.  `work` must point at 8 zeroed ints, kCursorStride apart (the persistent kernel's
+// ray cursors).  mode: kProd / kCountRef / kCountWork.
+inline void launch_extend(const DeviceCtx &dc, int mode, const f4 *ro, const f4 *rd, const int *queue, const int *count_ptr,
                           int n_fixed, int64_t n_max, HitRec *hits, int *work, unsigned long long *ctr, bool coherent_queue = false,
                           int common_origin = 0) {  // (common_origin != 0: persistent kernel only)
     ExtendTuning tune = coherent_queue ? dc.tune_coherent : dc.tune;
     tune.common_origin = common_origin;
+    tune.n_heads = dc.n_heads;
+    const bool count = mode == kCountRef;
     if (dc.extend_simple) {
         const int64_t want = (n_max + kExtendBlock - 1) / kExtendBlock;
         const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(want, (int64_t)dc.num_cus * 8));
@@ -358,18 +397,21 @@ inline void launch_extend(const DeviceCtx &dc, bool count, const f4 *ro, const f
     }
     const int64_t want = (n_max + kExtendBlock - 1) / kExtendBlock;
     const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(want, (int64_t)dc.num_cus * dc.extend_blocks_per_cu));
-    if (count)
-        hipLaunchKernelGGL(k_extend<true>, dim3(grid), dim3(kExtendBlock), 0, dc.stream, dc.view, ro, rd, queue, count_ptr,
+    if (mode == kCountRef)
+        hipLaunchKernelGGL(k_extend<kCountRef>, dim3(grid), dim3(kExtendBlock), 0, dc.stream, dc.view, ro, rd, queue, count_ptr,
+                           n_fixed, hits, work, ctr, tune);
+    else if (mode == kCountWork)
+        hipLaunchKernelGGL(k_extend<kCountWork>, dim3(grid), dim3(kExtendBlock), 0, dc.stream, dc.view, ro, rd, queue, count_ptr,
                            n_fixed, hits, work, ctr, tune);
     else
-        hipLaunchKernelGGL(k_extend<false>, dim3(grid), dim3(kExtendBlock), 0, dc.stream, dc.view, ro, rd, queue, count_ptr,
+        hipLaunchKernelGGL(k_extend<kProd>, dim3(grid), dim3(kExtendBlock), 0, dc.stream, dc.view, ro, rd, queue, count_ptr,
                            n_fixed, hits, work, ctr, tune);
 }
 
 // Resident 256-thread blocks per CU of the persistent kernel (occupancy API, capped like the hardware admits).
 inline int query_extend_blocks_per_cu() {
     int nb = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_extend<false>, kExtendBlock, 0) != hipSuccess || nb <= 0) nb = 4;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_extend<kProd>, kExtendBlock, 0) != hipSuccess || nb <= 0) nb = 4;
     return std::min(nb, 8);
 }
 

@@ -641,6 +641,121 @@ bool HostScene::pack(int n_threads, std::string &err) {
     return true;
 }
 
+// ------------------------------------------------------------------------------------------ export / import
+namespace {
+constexpr uint64_t kBlobMagic = 0x31424f4c4254504dull;  // "MPTBLOB1"
+struct BlobHeader {
+    uint64_t magic, struct_bytes, arena_bytes;
+    ArenaLayout layout;
+    int64_t total_tris, total_nodes, total_refs;
+    int32_t n_materials, n_lights, n_planes, n_spheres, n_meshes;
+    int32_t env_w, env_h, env_is_rgbe, cam_set;
+    float cam[12];
+    double build_seconds;
+};
+struct BlobMesh {
+    int64_t n_tris, tri_base, node_base, ref_base, n_nodes, n_refs, degenerate_nodes, n_leaves, max_leaf;
+    int32_t material, max_depth;
+};
+}  // namespace
+
+size_t export_blob(const HostScene &s, uint8_t *out) {
+    const size_t total = sizeof(BlobHeader) + s.meshes.size() * sizeof(BlobMesh) + s.arena.size();
+    if (!out) return total;
+    BlobHeader h;
+    memset(&h, 0, sizeof(h));
+    h.magic = kBlobMagic;
+    h.struct_bytes = sizeof(BlobHeader) + ((uint64_t)sizeof(BlobMesh) << 32);
+    h.arena_bytes = s.arena.size();
+    h.layout = s.layout;
+    h.total_tris = s.total_tris; h.total_nodes = s.total_nodes; h.total_refs = s.total_refs;
+    h.n_materials = (int32_t)s.materials.size(); h.n_lights = (int32_t)s.lights.size(); h.n_planes = (int32_t)s.planes.size();
+    h.n_spheres = (int32_t)s.spheres.size(); h.n_meshes = (int32_t)s.meshes.size();
+    h.env_w = s.env.w; h.env_h = s.env.h; h.env_is_rgbe = s.env.rgbe.empty() ? 0 : 1; h.cam_set = s.cam_set ? 1 : 0;
+    for (int k = 0; k < 3; k++) { h.cam[k] = s.cam_eye[k]; h.cam[3 + k] = s.cam_lookat[k]; h.cam[6 + k] = s.cam_right[k]; h.cam[9 + k] = s.cam_up[k]; }
+    h.build_seconds = s.build_seconds;
+    memcpy(out, &h, sizeof(h));
+    uint8_t *p = out + sizeof(h);
+    for (const HostMesh &m : s.meshes) {
+        BlobMesh bm;
+        memset(&bm, 0, sizeof(bm));
+        bm.n_tris = m.n_tris; bm.tri_base = m.tri_base; bm.node_base = m.node_base; bm.ref_base = m.ref_base; bm.n_nodes = m.n_nodes;
+        bm.n_refs = m.n_refs; bm.degenerate_nodes = m.degenerate_nodes; bm.n_leaves = m.n_leaves; bm.max_leaf = m.max_leaf;
+        bm.material = m.material; bm.max_depth = m.max_depth;
+        memcpy(p, &bm, sizeof(bm));
+        p += sizeof(bm);
+    }
+    memcpy(p, s.arena.data(), s.arena.size());
+    return total;
+}
+
+bool import_blob(HostScene &s, const uint8_t *blob, size_t size, std::string &err) {
+    BlobHeader h;
+    if (size < sizeof(h)) { err = "scene blob too small"; return false; }
+    memcpy(&h, blob, sizeof(h));
+    if (h.magic != kBlobMagic || h.struct_bytes != sizeof(BlobHeader) + ((uint64_t)sizeof(BlobMesh) << 32)) {
+        err = "not a scene blob of this library version";
+        return false;
+    }
+    if (h.n_meshes < 0 || h.n_materials < 0 || h.n_lights < 0 || h.n_planes < 0 || h.n_spheres < 0 ||
+        size != sizeof(h) + (size_t)h.n_meshes * sizeof(BlobMesh) + h.arena_bytes || h.layout.total != h.arena_bytes) {
+        err = "scene blob is truncated or inconsistent";
+        return false;
+    }
+    const ArenaLayout &L = h.layout;
+    const size_t offs[] = {L.nodes, L.boxes, L.tight, L.tight_pairs, L.refs, L.leaf_planes, L.leaf_spheres, L.leaf_verts, L.tri_pos,
+                           L.tri_nrm, L.meshes, L.mesh_order, L.spheres, L.planes, L.lights, L.materials, L.env};
+    for (size_t o : offs)
+        if (o > h.arena_bytes) { err = "scene blob: section outside the arena"; return false; }
+    s = HostScene();
+    // the small tables are read back from the arena sections the packer wrote them to
+    const uint8_t *p = blob + sizeof(h);
+    s.meshes.resize((size_t)h.n_meshes);
+    for (HostMesh &m : s.meshes) {
+        BlobMesh bm;
+        memcpy(&bm, p, sizeof(bm));
+        p += sizeof(bm);
+        m.n_tris = bm.n_tris; m.tri_base = bm.tri_base; m.node_base = bm.node_base; m.ref_base = bm.ref_base; m.n_nodes = bm.n_nodes;
+        m.n_refs = bm.n_refs; m.degenerate_nodes = bm.degenerate_nodes; m.n_leaves = bm.n_leaves; m.max_leaf = bm.max_leaf;
+        m.material = bm.material; m.max_depth = bm.max_depth;
+    }
+    s.arena.assign(p, p + h.arena_bytes);
+    const uint8_t *A = s.arena.data();
+    auto f = [&](size_t off, size_t i) { float v; memcpy(&v, A + off + 4 * i, 4); return v; };
+    auto iv = [&](size_t off, size_t i) { int32_t v; memcpy(&v, A + off + 4 * i, 4); return v; };
+    s.materials.resize((size_t)h.n_materials);
+    for (size_t i = 0; i < s.materials.size(); i++)
+        for (int k = 0; k < 3; k++) { s.materials[i].kd[k] = f(L.materials, 8 * i + k); s.materials[i].ks[k] = f(L.materials, 8 * i + 4 + k); }
+    s.lights.resize((size_t)h.n_lights);
+    for (size_t i = 0; i < s.lights.size(); i++)
+        for (int k = 0; k < 3; k++) { s.lights[i].loc[k] = f(L.lights, 8 * i + k); s.lights[i].power[k] = f(L.lights, 8 * i + 4 + k); }
+    s.planes.resize((size_t)h.n_planes);
+    for (size_t i = 0; i < s.planes.size(); i++) {
+        for (int k = 0; k < 3; k++) { s.planes[i].point[k] = f(L.planes, 8 * i + k); s.planes[i].normal[k] = f(L.planes, 8 * i + 4 + k); }
+        s.planes[i].material = iv(L.planes, 8 * i + 3);
+    }
+    s.spheres.resize((size_t)h.n_spheres);
+    for (size_t i = 0; i < s.spheres.size(); i++) {
+        for (int k = 0; k < 3; k++) s.spheres[i].center[k] = f(L.spheres, 8 * i + k);
+        s.spheres[i].radius = f(L.spheres, 8 * i + 3);
+        s.spheres[i].material = iv(L.spheres, 8 * i + 4);
+    }
+    s.env.w = h.env_w;
+    s.env.h = h.env_h;
+    if (h.env_w > 0) {  // view() only asks which of the two forms is present; the texels stay in the arena
+        if (h.env_is_rgbe) s.env.rgbe.assign(1, 0u);
+        else s.env.f32.assign(1, 0.0f);
+    }
+    s.cam_set = h.cam_set != 0;
+    for (int k = 0; k < 3; k++) { s.cam_eye[k] = h.cam[k]; s.cam_lookat[k] = h.cam[3 + k]; s.cam_right[k] = h.cam[6 + k]; s.cam_up[k] = h.cam[9 + k]; }
+    s.layout = L;
+    s.total_tris = h.total_tris; s.total_nodes = h.total_nodes; s.total_refs = h.total_refs;
+    s.build_seconds = h.build_seconds;
+    s.packed = true;
+    s.imported = true;
+    return true;
+}
+
 DScene HostScene::view(const void *base_v) const {
     const uint8_t *base = static_cast<const uint8_t *>(base_v);
     DScene d;

@@ -45,6 +45,7 @@ struct HostScene {
     HostEnv env;
 
     bool packed = false;
+    bool imported = false;       // packed state came from mipt_scene_import: no triangle arrays on the host, nothing to rebuild
     std::vector<uint8_t> arena;  // host copy of the device arena
     ArenaLayout layout;
     int64_t total_tris = 0, total_nodes = 0, total_refs = 0;
@@ -55,6 +56,11 @@ struct HostScene {
     // View whose pointers are `base` + section offsets (base = arena.data() for the host view).
     DScene view(const void *base) const;
 };
+
+// Flat serialised form of a packed scene (mipt_scene_export / _import): header + tables + the arena.  With out == nullptr
+// only the size is computed.  import_blob leaves `s` packed and `imported` (no triangle arrays, commit only uploads).
+size_t export_blob(const HostScene &s, uint8_t *out);
+bool import_blob(HostScene &s, const uint8_t *blob, size_t size, std::string &err);
 
 void camera_set(HostScene &s, const float eye[3], const float lookat[3], const float vup[3], float fov);
 bool load_obj(const char *path, const float position[3], const float rotate[3], const float scale[3], HostMesh &out,

@@ -26,6 +26,11 @@ struct TravCounters {
     unsigned int culled;                   // candidates of those that the leaf cull skipped
 };
 
+// What the production walk reads (k_extend<kCountWork>, MIPT_FLAG_WORK_COUNTERS): see mipt_stats.work_* in mipt.h.
+struct WorkCounters {
+    unsigned int steps, pops, sphere_pairs, planes, verts, leaves;
+};
+
 // Developer build only (make PHASE_STATS=1): per-phase SIMD-lane use of the persistent extend kernel.
 // exec[i] counts wave-level executions of phase i, lanes[i] the lanes active in them.
 #ifdef MIPT_PHASE_STATS
@@ -272,12 +277,13 @@ PT_HD void pair_culled(f4 bx, f4 by, f4 bz, f3 o, f3 d, bool &cull_l, bool &cull
 // the accepted hit at which the reference ENDS this mesh's search (Q8).  `taint_bit` of `flags` records that such a
 // child was dropped; if the search then still comes up with a hit that would be used, the caller repeats the mesh without
 // pruning (rare: it takes a leaf order that is not front to back).
-template <class Stack>
+template <class Stack, bool WORK = false>
 PT_HD bool descend_fast(const DScene &sc, f3 o, f3 d, SlabBox &cur, int &node, KdNode &nd, int &sp, Stack &stk,
-                        int max_steps, bool prune, float t_prune, uint32_t &flags, uint32_t taint_bit PSTAT_ARG) {
+                        int max_steps, bool prune, float t_prune, uint32_t &flags, uint32_t taint_bit, WorkCounters &wc PSTAT_ARG) {
     const float inf = __builtin_inff();
     for (int step = 0; (nd.b >> 30) != 3u && step < max_steps; step++) {
         PSTAT(ps, 9);
+        if (WORK) wc.steps++;
         const uint32_t ax = nd.b >> 30;
         const bool recheck = (nd.b & kRecheckBit) != 0u;
         const int left = (int)(nd.b & kIdxMask), right = left + 1;
@@ -428,7 +434,8 @@ PT_HD bool mesh_skippable(const DScene &sc, int root, f3 o, f3 d, float t_max) {
     return out | beyond | (tn > tf + 2.44140625e-4f * (fabsf(tf) + 1.0f)) | !(lo[0] <= hi[0]);
 }
 
-PT_HD void leaf_scan(const DScene &sc, int first, int count, f3 o, f3 d, const SlabBox &cur, float &bt, int &bi PSTAT_ARG);
+template <bool WORK>
+PT_HD void leaf_scan(const DScene &sc, int first, int count, f3 o, f3 d, const SlabBox &cur, float &bt, int &bi, WorkCounters &wc PSTAT_ARG);
 
 template <bool COUNT>
 PT_HD void leaf_closest(const DScene &sc, int node, KdNode nd, f3 o, f3 d, const SlabBox &cur, float &bt, int &bi,
@@ -442,7 +449,8 @@ PT_HD void leaf_closest(const DScene &sc, int node, KdNode nd, f3 o, f3 d, const
         return;
     }
     PSTAT_LOCAL
-    leaf_scan(sc, (int)nd.a, count, o, d, cur, bt, bi PSTAT_PASS);
+    WorkCounters wc = {0u, 0u, 0u, 0u, 0u, 0u};
+    leaf_scan<false>(sc, (int)nd.a, count, o, d, cur, bt, bi, wc PSTAT_PASS);
 }
 
 // Candidate pre-test (no counterpart in the reference; it changes no result).  A SpherePair holds, for two
@@ -471,9 +479,11 @@ PT_HD uint32_t sphere_pair_hit(const SpherePair s, f3 o, f3 d) {
 // passes: a few per leaf.  Pass 2 gives the marked ones the reference's evaluation in leaf order (the sequential
 // "t < best" rule keeps the earliest of equal hits); the lanes of a wave run it together instead of each branching
 // out of pass 1 on its own.
-PT_HD void leaf_scan(const DScene &sc, int first, int count, f3 o, f3 d, const SlabBox &cur, float &bt, int &bi PSTAT_ARG) {
+template <bool WORK>
+PT_HD void leaf_scan(const DScene &sc, int first, int count, f3 o, f3 d, const SlabBox &cur, float &bt, int &bi, WorkCounters &wc PSTAT_ARG) {
     bt = -1.0f;
     bi = -1;
+    if (WORK) wc.leaves++;
     const int end = first + count;
     for (int base = first & ~1; base < end; base += 64) {
         const int stop = (end - base < 64) ? end - base : 64;  // bits [max(first-base,0), stop) belong to this leaf
@@ -482,6 +492,7 @@ PT_HD void leaf_scan(const DScene &sc, int first, int count, f3 o, f3 d, const S
         for (int p = 0; 2 * p < stop; p += 2) {
             PSTAT(ps, 5);
             const SpherePair s0 = sp[p], s1 = sp[p + 1];
+            if (WORK) wc.sphere_pairs += 2;
             marked |= (unsigned long long)(sphere_pair_hit(s0, o, d) | (sphere_pair_hit(s1, o, d) << 2)) << (2 * p);
         }
         marked &= (stop < 64 ? (1ull << stop) - 1ull : ~0ull) & ~((1ull << (first > base ? first - base : 0)) - 1ull);
@@ -491,7 +502,9 @@ PT_HD void leaf_scan(const DScene &sc, int first, int count, f3 o, f3 d, const S
             marked &= marked - 1ull;
             const f4 pl = sc.leaf_planes[r];
             const float t = plane_candidate(pl, o, d, cur, bt);
+            if (WORK) wc.planes++;
             if (t > 0.0f) {
+                if (WORK) wc.verts++;
                 const f4 pa = sc.leaf_verts[3 * (size_t)r], pb = sc.leaf_verts[3 * (size_t)r + 1], pc = sc.leaf_verts[3 * (size_t)r + 2];
                 if (inside_triangle(pl, mk3(pa.x, pa.y, pa.z), mk3(pb.x, pb.y, pb.z), mk3(pc.x, pc.y, pc.z), o, d, t)) {
                     bt = t;

@@ -246,7 +246,7 @@ struct WfBuffers {
     uint32_t *q_light_key;       // light index << 24 | direction cell of each queued first light ray, or null
     int *q_ext_cam, *q_ext_light;           // the subset of camera / light rays that needs the extend kernel
     int *counts;                 // per-stage queue counts of the current pass
-    unsigned long long *totals;  // [0] camera rays [1] shadow rays [2] light rays [3] rays traced by k_extend
+    unsigned long long *totals;  // [0] camera rays [1] shadow rays [2] light rays [3] rays traced by k_extend [4] non-finite samples
     f4 *lv_pos, *lv_nrm, *lv_T;  // light vertices [path*Dl + j]: (pos, valid) (normal, pdf) (throughput, -)
     f4 *l_o, *l_d, *l_state;     // light rays; l_state = (emission dir, pdf carried to the next vertex)
     HitRec *l_hit;
@@ -256,12 +256,17 @@ struct WfBuffers {
 constexpr int kCntCam = 0;      // + i  (camera queue feeding vertex i), i <= 16
 constexpr int kCntShadow = 20;  // + i
 constexpr int kCntLight = 40;   // + i
-constexpr int kCntWork = 64;    // + launch index within the pass: ray cursor of each persistent extend launch
 constexpr int kCntExtCam = 128;     // + i: camera rays of vertex i that need the extend kernel (not trivially decided)
 constexpr int kCntExtLight = 148;   // + i
 constexpr int kCntShadowTriv = 168; // + i: shadow rays answered on the spot
+constexpr int kCntNonFinite = 188;  // samples of the pass whose radiance is not finite
 constexpr int kCntTotal = 192;
 constexpr int kCntPad = 64;  // counters sit 256 B apart: atomics on neighbouring words of one line serialise like same-address ones
+// behind the table: the 8 ray cursors of every persistent extend launch of the pass (launch index * 8 + range)
+constexpr int kCntWork = kCntTotal;
+constexpr int kMaxLaunches = 3 * kMaxPathDepth;
+constexpr int kCntSlots = kCntWork + 8 * kMaxLaunches;
+static_assert(kCntPad == kCursorStride, "launch_extend expects its 8 cursors one counter slot apart");
 
 __global__ __launch_bounds__(kBlock) void k_raygen(DScene sc, PassParams pp, WfBuffers b) {
     __shared__ int ap_lds[2 * (kWaves + 1)];
@@ -650,21 +655,32 @@ __global__ __launch_bounds__(kBlock) void k_resolve_queue(DScene sc, WfBuffers b
 }
 
 // image[id] += trace / nSamples, samples in increasing order (kernel.cu:339-343)
-__global__ __launch_bounds__(kBlock) void k_accumulate(PassParams pp, WfBuffers b, float *accum) {
+// A sample whose radiance is not finite (kept quirk, see DESIGN.md 2: the reference's arithmetic can produce one) is
+// counted; with drop_nonfinite (MIPT_FLAG_DROP_NONFINITE, an opt-in deviation) it adds nothing to the pixel.
+__global__ __launch_bounds__(kBlock) void k_accumulate(PassParams pp, WfBuffers b, float *accum, int drop_nonfinite) {
     const int pixel = blockIdx.x * kBlock + threadIdx.x;
-    if (pixel >= pp.npix) return;
-    const int pos = position_of(pp, pixel);
-    float ax = accum[3 * (size_t)pixel], ay = accum[3 * (size_t)pixel + 1], az = accum[3 * (size_t)pixel + 2];
-    const float ns = (float)pp.spp;
-    for (int s = 0; s < pp.n_slots; s++) {
-        const f4 r = b.path_rad[(size_t)s * pp.npix + pos];
-        ax = ax + r.x / ns;
-        ay = ay + r.y / ns;
-        az = az + r.z / ns;
+    int bad = 0;
+    if (pixel < pp.npix) {
+        const int pos = position_of(pp, pixel);
+        float ax = accum[3 * (size_t)pixel], ay = accum[3 * (size_t)pixel + 1], az = accum[3 * (size_t)pixel + 2];
+        const float ns = (float)pp.spp;
+        for (int s = 0; s < pp.n_slots; s++) {
+            const f4 r = b.path_rad[(size_t)s * pp.npix + pos];
+            const bool finite = (fabsf(r.x) < __builtin_inff()) & (fabsf(r.y) < __builtin_inff()) & (fabsf(r.z) < __builtin_inff());
+            bad += finite ? 0 : 1;
+            if (!finite && drop_nonfinite) continue;
+            ax = ax + r.x / ns;
+            ay = ay + r.y / ns;
+            az = az + r.z / ns;
+        }
+        accum[3 * (size_t)pixel] = ax;
+        accum[3 * (size_t)pixel + 1] = ay;
+        accum[3 * (size_t)pixel + 2] = az;
     }
-    accum[3 * (size_t)pixel] = ax;
-    accum[3 * (size_t)pixel + 1] = ay;
-    accum[3 * (size_t)pixel + 2] = az;
+    if (__ballot(bad != 0) != 0ull) {  // rare: one atomic per wave that saw one
+        bad = wave_sum_i(bad);
+        if ((threadIdx.x & 63u) == 0) atomicAdd(&b.counts[kCntPad * kCntNonFinite], bad);
+    }
 }
 
 __global__ void k_tally(WfBuffers b, int Dc, int Dl) {
@@ -678,6 +694,7 @@ __global__ void k_tally(WfBuffers b, int Dc, int Dl) {
     b.totals[1] += sh;
     b.totals[2] += li;
     b.totals[3] += ext;
+    b.totals[4] += (unsigned long long)b.counts[kCntPad * kCntNonFinite];
 }
 
 __global__ __launch_bounds__(kBlock) void k_env_lookup(DScene sc, const float *dirs, int64_t n, float *rgb) {
@@ -742,7 +759,7 @@ int wavefront_render(const HostScene &hs, DeviceCtx &dc, const mipt_render_confi
     sizes[14] = P * K * sizeof(HitRec);                             // sh_hit
     sizes[15] = P * K * 4;                                          // q_shadow
     sizes[16] = P * 4;                                              // q_ext_cam
-    sizes[17] = (size_t)kCntTotal * kCntPad * 4 + 64;               // counts + totals
+    sizes[17] = (size_t)kCntSlots * kCntPad * 4 + 64;               // counts + ray cursors + totals
     if (Dl > 0) {
         sizes[18] = sizes[19] = sizes[20] = P * Dl * sizeof(f4);    // lv_pos, lv_nrm, lv_T
         sizes[21] = sizes[22] = sizes[24] = P * sizeof(f4);         // l_o, l_d, l_state
@@ -774,7 +791,7 @@ int wavefront_render(const HostScene &hs, DeviceCtx &dc, const mipt_render_confi
     b.sh_o = dc.wf[10].as<f4>(); b.sh_d = dc.wf[11].as<f4>(); b.sh_target = dc.wf[12].as<f4>(); b.sh_contrib = dc.wf[13].as<f4>();
     b.sh_hit = dc.wf[14].as<HitRec>(); b.q_shadow = dc.wf[15].as<int>(); b.q_ext_cam = dc.wf[16].as<int>();
     b.counts = dc.wf[17].as<int>();
-    b.totals = reinterpret_cast<unsigned long long *>(dc.wf[17].as<char>() + (size_t)kCntTotal * kCntPad * 4 + 8);
+    b.totals = reinterpret_cast<unsigned long long *>(dc.wf[17].as<char>() + (size_t)kCntSlots * kCntPad * 4 + 8);
     b.lv_pos = dc.wf[18].as<f4>(); b.lv_nrm = dc.wf[19].as<f4>(); b.lv_T = dc.wf[20].as<f4>();
     b.l_o = dc.wf[21].as<f4>(); b.l_d = dc.wf[22].as<f4>(); b.l_hit = dc.wf[23].as<HitRec>(); b.l_state = dc.wf[24].as<f4>();
     b.path_rng = dc.wf[25].as<uint32_t>(); b.q_cam0 = dc.wf[26].as<int>();
@@ -786,8 +803,9 @@ int wavefront_render(const HostScene &hs, DeviceCtx &dc, const mipt_render_confi
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ext_ev;
     hipStream_t sm = dc.stream;
     WF_TRY(hipMemsetAsync(dc.wf[17].p, 0, sizes[17], sm));
-    const bool count_mode = (cfg.flags & MIPT_FLAG_COUNTERS) != 0;
-    if (count_mode) WF_TRY(hipMemsetAsync(dc.counters.p, 0, 64, sm));
+    const int mode = extend_mode(cfg.flags);
+    const bool count_mode = mode == kCountRef;
+    if (mode != kProd) WF_TRY(hipMemsetAsync(dc.counters.p, 0, kCtrCursor, sm));
     hipEvent_t ev_begin = dc.events.next(), ev_end = dc.events.next();
     WF_TRY(hipEventRecord(ev_begin, sm));
 
@@ -809,13 +827,12 @@ int wavefront_render(const HostScene &hs, DeviceCtx &dc, const mipt_render_confi
                       int common_origin = 0) {
         hipEvent_t a = dc.events.next(), e = dc.events.next();
         (void)hipEventRecord(a, sm);
-        launch_extend(dc, count_mode, ro, rd, queue, count, 0, (int64_t)n_max, hits, &b.counts[kCntPad * (kCntWork + (n_launch++))],
+        launch_extend(dc, mode, ro, rd, queue, count, 0, (int64_t)n_max, hits, &b.counts[kCntPad * (kCntWork + 8 * (n_launch++))],
                       dc.counters.as<unsigned long long>(), coherent_queue, common_origin);
         (void)hipEventRecord(e, sm);
         ext_ev.emplace_back(a, e);
     };
     const int path_grid = (int)std::min<size_t>((P + kBlock - 1) / kBlock, (size_t)dc.num_cus * 16);
-    static_assert(3 * kMaxPathDepth <= kCntTotal - kCntWork, "work cursor table too small");
 
     PassParams pp;
     pp.W = cfg.width; pp.H = cfg.height; pp.npix = npix; pp.spp = cfg.spp; pp.sample_stride = stride;
@@ -828,7 +845,7 @@ int wavefront_render(const HostScene &hs, DeviceCtx &dc, const mipt_render_confi
         pp.sample0 = cfg.sample_begin + (int)done * stride;
         const size_t np = (size_t)pp.n_slots * npix;
         const unsigned full_grid = (unsigned)((np + kBlock - 1) / kBlock);
-        WF_TRY(hipMemsetAsync(b.counts, 0, (size_t)kCntTotal * kCntPad * 4, sm));
+        WF_TRY(hipMemsetAsync(b.counts, 0, (size_t)kCntSlots * kCntPad * 4, sm));
         n_launch = 0;
         hipLaunchKernelGGL(k_raygen, dim3(full_grid), dim3(kBlock), 0, sm, dc.view, pp, b);
         if (Dl > 0) {
@@ -858,7 +875,8 @@ int wavefront_render(const HostScene &hs, DeviceCtx &dc, const mipt_render_confi
             else hipLaunchKernelGGL(k_resolve, dim3(path_grid), dim3(kBlock), 0, sm, dc.view, pp, b, i);
             // the shadow queue is refilled from slot 0 by the next vertex: its count lives in its own slot
         }
-        hipLaunchKernelGGL(k_accumulate, dim3((unsigned)((npix + kBlock - 1) / kBlock)), dim3(kBlock), 0, sm, pp, b, d_accum);
+        hipLaunchKernelGGL(k_accumulate, dim3((unsigned)((npix + kBlock - 1) / kBlock)), dim3(kBlock), 0, sm, pp, b, d_accum,
+                           (cfg.flags & MIPT_FLAG_DROP_NONFINITE) ? 1 : 0);
         hipLaunchKernelGGL(k_tally, dim3(1), dim3(64), 0, sm, b, Dc, Dl);
         WF_TRY(hipGetLastError());
     }
@@ -883,7 +901,7 @@ int wavefront_render(const HostScene &hs, DeviceCtx &dc, const mipt_render_confi
         fprintf(stderr, "\n");
     }
     if (st) {
-        unsigned long long tot[4] = {0, 0, 0, 0};
+        unsigned long long tot[5] = {0, 0, 0, 0, 0};
         WF_TRY(hipMemcpy(tot, b.totals, sizeof(tot), hipMemcpyDeviceToHost));
         float ms = 0.f;
         WF_TRY(hipEventElapsedTime(&ms, ev_begin, ev_end));
@@ -897,6 +915,7 @@ int wavefront_render(const HostScene &hs, DeviceCtx &dc, const mipt_render_confi
         st->rays_shadow = (int64_t)tot[1];
         st->rays_light = (int64_t)tot[2];
         st->rays_extended = (int64_t)tot[3];
+        st->nonfinite_samples = (int64_t)tot[4];
         st->rays_total = st->rays_camera + st->rays_shadow + st->rays_light;
         st->samples = n_samples * npix;
         st->extend_launches = (int64_t)ext_ev.size();
@@ -909,6 +928,7 @@ int wavefront_render(const HostScene &hs, DeviceCtx &dc, const mipt_render_confi
             st->ctr_nodes = (int64_t)c[0]; st->ctr_pops = (int64_t)c[1]; st->ctr_refs = (int64_t)c[2];
             st->ctr_tris = (int64_t)c[3]; st->ctr_hits = (int64_t)c[4]; st->ctr_culled = (int64_t)c[5];
         }
+        if (mode == kCountWork) fill_work_counters(dc, st);
     }
     return 0;
 }

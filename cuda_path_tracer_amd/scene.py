@@ -15,7 +15,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from ._lib import FLAG_COUNTERS, RenderConfig, Stats, check
+from ._lib import FLAG_COUNTERS, FLAG_WORK_COUNTERS, RenderConfig, Stats, check
 
 
 def _f3(v):
@@ -101,6 +101,23 @@ class Scene:
         check(self._lib.mipt_scene_commit(self._h, arr, len(devices)))
         self.devices = devices
 
+    def export_blob(self):
+        """The packed scene (kd-trees, leaf records, tables, cube map) as one uint8 array: build on one rank, broadcast,
+        `import_blob` + `commit` on the others (no second kd build)."""
+        n = check(self._lib.mipt_scene_export_size(self._h))
+        blob = np.empty(n, dtype=np.uint8)
+        check(self._lib.mipt_scene_export(self._h, _ptr(blob), n))
+        return blob
+
+    def import_blob(self, blob):
+        blob = np.ascontiguousarray(blob, dtype=np.uint8)
+        check(self._lib.mipt_scene_import(self._h, _ptr(blob), blob.size))
+        self.devices = []
+
+    def set_caller_stream(self, stream_handle, dev_slot=0):
+        """hipStream_t (as an integer; 0 = the default stream) whose queued work the *_device calls wait for on entry."""
+        check(self._lib.mipt_scene_set_caller_stream(self._h, int(dev_slot), C.c_void_p(int(stream_handle) or None)))
+
     # ---- rendering --------------------------------------------------------------------------
     def render(self, cfg):
         """Returns (image float32 (H, W, 3), stats dict)."""
@@ -115,7 +132,7 @@ class Scene:
         check(self._lib.mipt_render_device(self._h, int(dev_slot), C.byref(cfg), C.c_void_p(int(accum_ptr)), C.byref(st)))
         return st.as_dict()
 
-    def trace_closest(self, ray_o, ray_d, counters=False):
+    def trace_closest(self, ray_o, ray_d, counters=False, work_counters=False):
         """Closest hit of Ray(o, d) for host arrays (n, 3).  Returns (prim int32 (n,), t float32 (n,), stats)."""
         ray_o = np.ascontiguousarray(ray_o, dtype=np.float32).reshape(-1, 3)
         ray_d = np.ascontiguousarray(ray_d, dtype=np.float32).reshape(-1, 3)
@@ -126,14 +143,15 @@ class Scene:
         t = np.empty(n, dtype=np.float32)
         st = Stats()
         check(self._lib.mipt_trace_closest(self._h, _ptr(ray_o), _ptr(ray_d), n, _ptr(prim), _ptr(t), C.byref(st),
-                                           FLAG_COUNTERS if counters else 0))
+                                           FLAG_COUNTERS if counters else (FLAG_WORK_COUNTERS if work_counters else 0)))
         return prim, t, st.as_dict()
 
-    def trace_closest_device(self, o_ptr, d_ptr, n, prim_ptr, t_ptr, counters=False, dev_slot=0):
+    def trace_closest_device(self, o_ptr, d_ptr, n, prim_ptr, t_ptr, counters=False, dev_slot=0, work_counters=False):
         st = Stats()
         check(self._lib.mipt_trace_closest_device(self._h, int(dev_slot), C.c_void_p(int(o_ptr)), C.c_void_p(int(d_ptr)),
                                                   int(n), C.c_void_p(int(prim_ptr)), C.c_void_p(int(t_ptr)),
-                                                  C.byref(st), FLAG_COUNTERS if counters else 0))
+                                                  C.byref(st),
+                                                  FLAG_COUNTERS if counters else (FLAG_WORK_COUNTERS if work_counters else 0)))
         return st.as_dict()
 
     def env_lookup(self, dirs):

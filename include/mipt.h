@@ -48,9 +48,23 @@ typedef struct mipt_stats {
     /* traversal counters, filled only when MIPT_FLAG_COUNTERS is requested (slower kernel):   */
     int64_t ctr_nodes, ctr_pops, ctr_refs, ctr_tris, ctr_hits;
     int64_t ctr_culled;      /* of ctr_tris: candidates skipped by the per-leaf cull box (never changes a result) */
+    /* samples whose radiance came out non-finite (the reference's arithmetic can divide by a vanishing pdf or take the
+     * sqrt of a tiny negative, samplers.cuh:19, kernel.cu:254,276; such a sample poisons image[id], kernel.cu:343) */
+    int64_t nonfinite_samples;
+    /* what the PRODUCTION closest-hit kernel read, filled only with MIPT_FLAG_WORK_COUNTERS (same results, slower): */
+    int64_t work_steps;      /* node steps: one 16-byte child pair + one 64-byte cull-box pair each            */
+    int64_t work_pops;       /* stack pops + mesh roots opened: one 8-byte node + one 32-byte box each         */
+    int64_t work_sphere_pairs; /* 32-byte candidate-sphere pairs streamed by the leaf scans                    */
+    int64_t work_planes;     /* marked candidates: one 16-byte plane record each                               */
+    int64_t work_verts;      /* of those, candidates that reached the edge tests: 48 bytes of vertices each    */
+    int64_t work_leaves;     /* leaf scans (one 4-byte reference -> triangle id lookup per scan with a hit)    */
 } mipt_stats;
 
-enum { MIPT_FLAG_COUNTERS = 1 };
+enum {
+    MIPT_FLAG_COUNTERS = 1,        /* reference-walk kernel + its counters (ctr_*)                                */
+    MIPT_FLAG_DROP_NONFINITE = 2,  /* opt-in deviation: a non-finite sample adds nothing to the image (still counted) */
+    MIPT_FLAG_WORK_COUNTERS = 4    /* production kernel + what it read (work_*)                                  */
+};
 
 /* ---- scene construction: replaces Scene::build (kernel.cu:52-142) --------------------- */
 int  mipt_scene_create(mipt_scene **out);                        /* `Scene scene;` kernel.cu:383 */
@@ -71,6 +85,13 @@ int  mipt_scene_add_mesh_obj(mipt_scene *, const char *path, const float positio
  * Faces are kept as raw RGBE (4 B/texel) and decoded in-kernel, bit-exact w.r.t. convertComponent HDRLoader.cu:99-104. */
 int  mipt_scene_set_envmap_rgbe_dir(mipt_scene *, const char *folder);
 int  mipt_scene_set_envmap_f32(mipt_scene *, const float *faces6, int w, int h);  /* six w*h*3 fp32 faces, order px,py,pz,nx,ny,nz */
+/* Build once, ship everywhere: the packed scene (one arena + its section table) as a flat blob.  A multi-process run
+ * builds the kd-trees on ONE rank, broadcasts the blob and imports it on the others instead of G contended host builds
+ * (the reference rebuilds everything per process: Scene::build kernel.cu:52-142 has no serialised form).  An imported scene
+ * is ready for mipt_scene_commit (which then only uploads); the blob is only valid for the library version that wrote it. */
+int64_t mipt_scene_export_size(mipt_scene *);                     /* bytes, after a commit (any n_devices); < 0 on error */
+int  mipt_scene_export(mipt_scene *, void *blob, int64_t size);
+int  mipt_scene_import(mipt_scene *, const void *blob, int64_t size);
 /* kd build (Mesh::getKdTree/Node::makeNodeTree mesh.cu:32-155) + flat SoA packing (8-byte nodes,
  * triangle index lists) + one arena upload per device.  Replaces every copyToDevice call site
  * (copyToDevice.h:8-55; kernel.cu:61-139, mesh.cu:35-36,176,200, envMap.cuh:27,31, intersectable.cuh:12).
@@ -84,6 +105,12 @@ int  mipt_render(mipt_scene *, const mipt_render_config *, float *out_rgb_f32, m
 /* Same on committed device slot `dev_slot`, ADDING into a caller-provided DEVICE buffer (W*H*3 fp32),
  * e.g. the tensor a caller then all-reduces over RCCL. Synchronises the scene stream before returning. */
 int  mipt_render_device(mipt_scene *, int dev_slot, const mipt_render_config *, float *d_accum_rgb, mipt_stats *out);
+/* Stream ordering of the *_device entry points (the reference has one stream, the default one: kernel.cu:397-416).  The
+ * library works on a private stream per device slot.  On entry it makes that stream wait for everything the caller has
+ * queued so far on `hip_stream` (a hipStream_t; NULL = the default stream, which is also what PyTorch uses unless told
+ * otherwise), so a producer kernel or a zero-fill of the accumulation buffer needs no host synchronisation; on return the
+ * library's work is complete (the stream has been synchronised), so consumers on any stream may follow.  */
+int  mipt_scene_set_caller_stream(mipt_scene *, int dev_slot, void *hip_stream);
 
 /* Closest hit for explicit rays: Scene::firstIntersect kernel.cu:145-160 on Ray(o, d) (ray.cuh:10 normalises d).
  * prim_id: -1 = miss, else triangles in mesh/face order, then spheres, then planes (Hit carries no id, hit.cuh:9-15). */

@@ -96,8 +96,47 @@ def test_cabi_exports_every_declared_symbol():
 
 
 def test_cabi_struct_sizes_match_header():
-    # mipt_render_config: 12 x int32; mipt_stats: 7 x int64 + 3 x double + 6 x int64
-    assert C.sizeof(_lib.RenderConfig) == 48 and C.sizeof(_lib.Stats) == 16 * 8
+    # mipt_render_config: 12 x int32; mipt_stats: 7 x int64 + 3 x double + 6 x int64 (ctr_*) + 1 + 6 x int64 (work_*)
+    assert C.sizeof(_lib.RenderConfig) == 48 and C.sizeof(_lib.Stats) == 23 * 8
+    hdr = open(os.path.join(ROOT, "include", "mipt.h")).read()
+    body = hdr[hdr.index("typedef struct mipt_stats"):hdr.index("} mipt_stats;")]
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    names = [n.strip() for decl in re.findall(r"(?:int64_t|double)\s+([^;]+);", body) for n in decl.split(",")]
+    assert names == [n for n, _ in _lib.Stats._fields_]
+
+
+def test_export_import_round_trip(cube_obj):
+    """mipt_scene_export / _import: the packed scene of one process, byte for byte, in another scene object -- the same
+    arena, the same kd-tree and triangles through the introspection calls, no rebuild; edits are refused."""
+    desc = G.scene_default(cube_obj)
+    pos, nrm = G.icosphere(3, 1.5, (0.0, -2.0, -1.0))
+    desc.meshes.append(("arrays", pos, nrm, 0))
+    desc.spheres.append(((1.0, 2.0, -1.0), 0.5, 1))
+    desc.env_f32 = G.synthetic_env_faces(4)
+    a = desc.apply(Scene())
+    a.commit(devices=())
+    blob = a.export_blob()
+    b = Scene()
+    b.import_blob(blob)
+    b.commit(devices=())
+    assert np.array_equal(b.export_blob(), blob)
+    assert b.mesh_count() == a.mesh_count() == 4 and b.device_bytes() == a.device_bytes()
+    for m in range(4):
+        ka, kb = a.kd_export(m), b.kd_export(m)
+        for k in ka:
+            assert np.array_equal(ka[k], kb[k]), (m, k)
+        for x, y in zip(a.mesh_triangles(m), b.mesh_triangles(m)):
+            assert np.array_equal(x, y)
+    with pytest.raises(_lib.MiptError, match="imported scene"):
+        b.add_material((1, 1, 1), (0, 0, 0))
+    with pytest.raises(_lib.MiptError, match="imported scene"):
+        b.add_mesh(pos, nrm, 0)
+    with pytest.raises(_lib.MiptError, match="blob"):
+        Scene().import_blob(blob[:-16])
+    bad = blob.copy()
+    bad[0] ^= 0xFF
+    with pytest.raises(_lib.MiptError, match="blob"):
+        Scene().import_blob(bad)
 
 
 def test_error_behaviour_without_device():
