@@ -88,6 +88,16 @@ __global__ __launch_bounds__(256) void k_add_into(float *__restrict__ dst, const
     if (i < n) dst[i] = dst[i] + src[i];
 }
 
+// ---- scratch of mipt_trace_closest_device_noalloc ------------------------------------------------------------------
+// A fixed device array instead of hipMalloc'ed work buffers: [0, 4 KiB) ray cursors + counters, then per ray the padded
+// origin (16 B), direction (16 B) and hit record (8 B).  Every GPU that loads the library holds its own copy (~40 MiB)
+// until the process ends; the array's NAME is a host-side stand-in -- host code uses the per-device address that
+// hipGetSymbolAddress returned at commit (DeviceCtx::noalloc_scratch), never the name.
+constexpr int64_t kNoAllocMaxRays = (int64_t)1 << 20;
+constexpr size_t kNoAllocHead = 4096;
+constexpr size_t kNoAllocBytes = kNoAllocHead + (size_t)kNoAllocMaxRays * (sizeof(f4) + sizeof(f4) + sizeof(HitRec));
+static __device__ __align__(256) unsigned char scratch[kNoAllocBytes];
+
 void release_device(DeviceCtx &dc) {
     if (dc.device < 0) return;
     (void)hipSetDevice(dc.device);
@@ -122,6 +132,7 @@ int setup_device(mipt_scene *s, DeviceCtx &dc) {
     HIP_TRY(hipStreamSynchronize(dc.stream));
     HIP_TRY(dc.counters.reserve(kCounterBytes));
     HIP_TRY(hipMemset(dc.counters.p, 0, kCounterBytes));
+    HIP_TRY(hipGetSymbolAddress((void **)&dc.noalloc_scratch, HIP_SYMBOL(scratch)));  // this device's copy of the array
     dc.extend_blocks_per_cu = query_extend_blocks_per_cu();
     const char *ev = getenv("MIPT_EXTEND");
     dc.extend_simple = ev && std::string(ev) == "simple";
@@ -373,6 +384,33 @@ int mipt_trace_closest_device(mipt_scene *s, int slot, const float *d_ray_o, con
 #ifdef MIPT_PHASE_STATS
     if (!count) dump_phase_stats(dc, "trace_closest");
 #endif
+    return 0;
+}
+
+int mipt_trace_closest_device_noalloc(mipt_scene *s, int slot, const float *d_ray_o, const float *d_ray_d, int64_t n,
+                                      int32_t *d_prim, float *d_t) {
+    if (!s || !s->committed) return fail(-1, "scene not committed");
+    if (slot < 0 || slot >= (int)s->devs.size()) return fail(-1, "scene is not committed on that device slot");
+    if (n < 0 || n > kNoAllocMaxRays)
+        return fail(-1, "ray count beyond the fixed scratch of the no-alloc entry point (at most 1048576 rays per call)");
+    if (n == 0) return 0;
+    if (!d_ray_o || !d_ray_d || !d_prim || !d_t) return fail(-1, "null buffer");
+    DeviceCtx &dc = s->devs[slot];
+    if (!dc.noalloc_scratch) return fail(-2, "scratch array address unknown on this device");
+    HIP_TRY(hipSetDevice(dc.device));
+    unsigned char *base = dc.noalloc_scratch;  // (the device address; `scratch` itself must not be used here)
+    f4 *ro = reinterpret_cast<f4 *>(base + kNoAllocHead);
+    f4 *rd = ro + kNoAllocMaxRays;
+    HitRec *hits = reinterpret_cast<HitRec *>(rd + kNoAllocMaxRays);
+    HIP_TRY(wait_for_caller(dc));
+    HIP_TRY(hipMemsetAsync(base, 0, kNoAllocHead, dc.stream));  // the cursors must start at zero; the rest is overwritten
+    const int blocks = (int)((n + 255) / 256);
+    hipLaunchKernelGGL(k_make_rays, dim3(blocks), dim3(256), 0, dc.stream, dc.view, d_ray_o, d_ray_d, n, ro, rd, hits);
+    launch_extend(dc, kProd, ro, rd, nullptr, nullptr, (int)n, n, hits, reinterpret_cast<int *>(base),
+                  reinterpret_cast<unsigned long long *>(base + 8 * 256));
+    hipLaunchKernelGGL(k_split_hits, dim3(blocks), dim3(256), 0, dc.stream, hits, n, d_prim, d_t);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(dc.stream));
     return 0;
 }
 

@@ -89,6 +89,7 @@ struct DeviceCtx {
     int shadow_sort_from = 1;      // MIPT_SHADOW_SORT=<vertex>: first camera vertex whose shadow rays are binned by direction (-1: never)
     // closest-hit work buffers
     DevBuf ray_o, ray_d, hits, io_a, io_b, io_c, io_d, counters;
+    unsigned char *noalloc_scratch = nullptr;  // device address of api.hip's fixed scratch array on this device
     DevBuf accum;  // mipt_render: this slot's partial framebuffer (W*H*3 fp32), reduced to slot 0 on the devices
     // wavefront work buffers (see wavefront.hip)
     DevBuf wf[36];

@@ -154,6 +154,11 @@ class Scene:
                                                   FLAG_COUNTERS if counters else (FLAG_WORK_COUNTERS if work_counters else 0)))
         return st.as_dict()
 
+    def trace_closest_device_noalloc(self, o_ptr, d_ptr, n, prim_ptr, t_ptr, dev_slot=0):
+        """Same results from the library's fixed scratch array: no allocation, at most 2**20 rays per call."""
+        check(self._lib.mipt_trace_closest_device_noalloc(self._h, int(dev_slot), C.c_void_p(int(o_ptr)), C.c_void_p(int(d_ptr)),
+                                                          int(n), C.c_void_p(int(prim_ptr)), C.c_void_p(int(t_ptr))))
+
     def env_lookup(self, dirs):
         dirs = np.ascontiguousarray(dirs, dtype=np.float32).reshape(-1, 3)
         rgb = np.empty_like(dirs)

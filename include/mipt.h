@@ -119,6 +119,13 @@ int  mipt_trace_closest(mipt_scene *, const float *ray_o, const float *ray_d, in
 /* Same with all four buffers resident on device slot `dev_slot` (n*3, n*3, n, n elements). */
 int  mipt_trace_closest_device(mipt_scene *, int dev_slot, const float *d_ray_o, const float *d_ray_d, int64_t n,
                                int32_t *d_prim_id, float *d_t, mipt_stats *out, int flags);
+/* No counterpart in the reference.  The same closest hit as mipt_trace_closest_device for callers that cannot allocate
+ * (code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc): it calls no hipMalloc / hipFree or
+ * any allocating routine.  Its work buffers (padded rays, hit records, ray cursors) live in a fixed device array inside
+ * the library (~40 MiB per GPU, held until the process ends), so n is limited to 1,048,576 rays per call (larger n: error).
+ * No statistics.  Every call on one GPU shares that array: calls that overlap on one GPU race -- serialise them. */
+int  mipt_trace_closest_device_noalloc(mipt_scene *, int dev_slot, const float *d_ray_o, const float *d_ray_d, int64_t n,
+                                       int32_t *d_prim_id, float *d_t);
 /* EnvMap::getPixelColor envMap.cuh:50-89 evaluated on the device for n directions (host buffers). */
 int  mipt_env_lookup(mipt_scene *, const float *dirs, int64_t n, float *rgb);
 
