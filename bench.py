@@ -3,22 +3,38 @@
 
 Workload (BASELINE.json configs[1], "C2"): box room + one kd-tree icosphere of 81,920 triangles, simple path
 tracing depth 6, 1920x1080.  One step = one pass of the hot path over one batch: `--spp-per-step` samples of
-every pixel on every rank (weak scaling: per-GPU work is fixed; the default K=32 x 8 spp = the config's 256 spp
-per GPU).  Ranks render interleaved sample indices of the SAME frame and the fp32 framebuffer is all-reduced
-once (RCCL) inside the timed region.  value = pixel-samples of all ranks / max-over-ranks wall time.
+every pixel on every rank (weak scaling: per-GPU work is fixed; the default 4 steps x 64 spp = the config's 256 spp
+per GPU).  Ranks render interleaved sample indices of the SAME frame and the fp32 framebuffer is all-reduced once
+(RCCL) inside the timed region.  value = pixel-samples of all ranks / max-over-ranks wall time.
+
+Launch: `python bench.py --gpus N` starts N rank processes itself (before anything touches a GPU) when it is not
+already running under torchrun (`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`); it
+refuses to run with fewer than N visible devices and never reports n_gpus != N.
 
 Extra objects on the JSON line:
-  roofline     dominant kernel k_extend (kd closest hit): algorithmic bytes (SURVEY 8d formula, per-ray means from
-               the in-kernel traversal counters of an untimed step of the same workload) / summed launch time (HIP
-               events on the library's stream) vs 8 TB/s HBM.
+  roofline     dominant kernel k_extend (kd closest hit), three views that each are a fraction of a real limit:
+               `hbm`   memory-side bytes (L2 misses x 128 B + writes, rocprofv3 --pmc passes run by this script in
+                       child processes before the timed part; calibration: profiles/r2_gather_calibration.txt) / launch
+                       time (HIP events) vs 8 TB/s;  `valu`  VALU busy fraction and lane use from the same passes;
+               `algorithmic` what the production kernel reads by its own layout (counted by k_extend<kCountWork> in an
+                       untimed step) -- memory-side / algorithmic < 1 is what the caches absorbed.
+               roofline.bound names the larger of the hbm and valu fractions; `reference_model` keeps SURVEY 8d's
+               reference-traversal byte model as a throughput normalisation (it is not a fraction of anything).
   cpu_baseline the CPU oracle ("port") rendering a bounded pixel-subsampled slice of the same workload.
   closest_hit  (N=1 only) Mrays/s of mipt_trace_closest_device on the 1,310,720-triangle icosphere (C4 mesh) for a
-               coherent and an incoherent batch of 2^24 rays, with the same roofline accounting.
+               coherent and an incoherent batch of 2^24 rays, with the same three roofline views each.
+  strong       (N>1 only) the same frame at FIXED total spp (what one GPU renders in the weak run) split over N ranks.
 """
 import argparse
+import csv
+import glob
 import json
 import os
+import shutil
+import socket
+import subprocess
 import sys
+import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -27,19 +43,138 @@ if ROOT not in sys.path:
 
 import numpy as np
 
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+HBM_MEASURED_COPY_GBS = 6300.0  # same guide: ~6.3 TB/s achievable by a streaming copy
+LINE_BYTES = 128               # one L2 miss fills one 128-byte line, for gathers as for streams (profiles/r2_gather_calibration.txt)
+
+PMC_PASSES = (
+    ("FETCH_SIZE", "TCC_MISS_sum"),
+    ("WRITE_SIZE", "TCC_HIT_sum", "TCC_MISS_sum"),
+    ("SQ_ACTIVE_INST_VALU", "SQ_THREAD_CYCLES_VALU", "SQ_INSTS_VALU", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "GRBM_GUI_ACTIVE"),
+)
 
 
 def bytes_per_ray(nodes, refs, tris, hit_frac):
-    """32 (ray in) + 16 (hit out) + 8*N_node + 4*N_ref + 36*N_tri + 36*[hit]."""
+    """SURVEY.md 8d (reference traversal): 32 (ray in) + 16 (hit out) + 8*N_node + 4*N_ref + 36*N_tri + 36*[hit]."""
     return 32.0 + 16.0 + 8.0 * nodes + 4.0 * refs + 36.0 * tris + 36.0 * hit_frac
+
+
+def product_bytes_per_ray(st, rays, origin_bytes=16.0, queue_bytes=4.0):
+    """What k_extend<kProd> reads and writes per ray by its own layout: per node step one 16-byte child
+    pair + one 64-byte cull-box pair; per stack pop / mesh root one 8-byte node + one 32-byte box; 32 bytes per streamed
+    candidate-sphere pair; 16 bytes per marked candidate's plane + 48 for the vertices of those that reach the edge
+    tests; ray in (16 direction [+ 16 origin] [+ 4 queue index] + 8 parked sphere/plane answer) and 8 hit out."""
+    rays = max(1, rays)
+    per = {k: st["work_" + k] / rays for k in ("steps", "pops", "sphere_pairs", "planes", "verts", "leaves")}
+    b = (80.0 * per["steps"] + 40.0 * per["pops"] + 32.0 * per["sphere_pairs"] + 16.0 * per["planes"] + 48.0 * per["verts"]
+         + 16.0 + origin_bytes + queue_bytes + 8.0 + 8.0)
+    return b, per
 
 
 def cpu_threads():
     return max(1, min(16, os.cpu_count() or 1))
 
 
-def closest_hit_bench(torch, G, Scene, FLAG_COUNTERS, n_rays, with_cpu):
+# ----------------------------------------------------------------------------------------------- PMC passes
+def collect_pmc(args, log):
+    """rocprofv3 --pmc passes over scripts/pmc_worker.py (the same C2 step and closest-hit batches), each in a child
+    process of its own, BEFORE this process touches the GPU.  Returns {part: {counter: mean per k_extend<0> launch}}
+    or (None, reason)."""
+    if shutil.which("rocprofv3") is None:
+        return None, "rocprofv3 not on PATH"
+    out = tempfile.mkdtemp(prefix="mipt_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    worker = os.path.join(ROOT, "scripts", "pmc_worker.py")
+    sums = {}
+    manifest = None
+    for i, ctrs in enumerate(PMC_PASSES):
+        mf = os.path.join(out, "manifest%d.json" % i)
+        cmd = ["timeout", "-s", "KILL", str(int(args.pmc_timeout)), "rocprofv3", "--pmc", *ctrs, "--output-format", "csv",
+               "-d", os.path.join(out, "p%d" % i), "--", sys.executable, worker, mf, "--spp", str(args.spp_per_step),
+               "--width", str(args.width), "--height", str(args.height), "--level", str(args.level)]
+        if args.no_closest:
+            cmd.append("--no-closest")
+        t0 = time.time()
+        with open(os.path.join(out, "p%d.log" % i), "w") as lf:
+            rc = subprocess.call(cmd, cwd="/tmp", env=env, stdout=lf, stderr=subprocess.STDOUT)
+        log("pmc pass %d (%s): rc %d, %.1f s" % (i, " ".join(ctrs), rc, time.time() - t0))
+        if rc != 0 or not os.path.exists(mf):
+            return None, "pmc pass %d failed (rc %d, see %s)" % (i, rc, out)
+        manifest = json.load(open(mf))["parts"]
+        rows = []
+        for f in glob.glob(os.path.join(out, "p%d" % i, "**", "*counter_collection.csv"), recursive=True):
+            for row in csv.DictReader(open(f)):
+                name = row["Kernel_Name"]
+                if "k_extend<0>" in name or "k_extend<(int)0>" in name:
+                    rows.append((int(row["Dispatch_Id"]), row["Counter_Name"], float(row["Counter_Value"])))
+        by_disp = {}
+        for d, c, v in rows:
+            by_disp.setdefault(d, {})[c] = by_disp.get(d, {}).get(c, 0.0) + v
+        order = sorted(by_disp)
+        if len(order) != sum(p["launches"] for p in manifest):
+            return None, "pmc pass %d: %d k_extend dispatches, manifest says %d" % (i, len(order), sum(p["launches"] for p in manifest))
+        at = 0
+        for p in manifest:
+            sel = order[at:at + p["launches"]]
+            at += p["launches"]
+            dst = sums.setdefault(p["name"], {"launches": p["launches"], "rays": p["rays"]})
+            for c in ctrs:
+                dst[c] = sum(by_disp[d].get(c, 0.0) for d in sel) / max(1, len(sel))
+    shutil.rmtree(out, ignore_errors=True)
+    return sums, "live: rocprofv3 --pmc passes over scripts/pmc_worker.py in this run"
+
+
+def roofline_views(pmc, launch_ms, rays_per_launch, alg_bpr, ref_bpr, extra=None):
+    """The three views of one kernel launch (see the module docstring).  pmc: per-launch counter means or None."""
+    sec = launch_ms * 1e-3
+    alg_bytes = alg_bpr * rays_per_launch
+    r = {"kernel": "k_extend", "avg_launch_ms": round(launch_ms, 4), "rays_per_launch": int(round(rays_per_launch)),
+         "Mrays_per_s_in_kernel": round(rays_per_launch / sec / 1e6, 1),
+         "algorithmic": {"bytes_per_ray": round(alg_bpr, 1), "bytes_per_launch": int(round(alg_bytes)),
+                         "GB_per_s": round(alg_bytes / sec / 1e9, 1),
+                         "note": "product-layout bytes the kernel asks for (k_extend<kCountWork>); served by L2 / Infinity Cache / HBM"},
+         "reference_model": {"bytes_per_ray": round(ref_bpr, 1), "GB_per_s": round(ref_bpr * rays_per_launch / sec / 1e9, 1),
+                             "x_hbm_peak": round(ref_bpr * rays_per_launch / sec / 1e9 / HBM_PEAK_GBS, 3),
+                             "note": "SURVEY 8d byte model of the REFERENCE's traversal over the same rays: a throughput "
+                                     "normalisation, not a fraction of a limit (the product skips ~90 % of those candidates)"}}
+    if extra:
+        r.update(extra)
+    if not pmc:
+        r.update({"bound": "hbm", "achieved": round(alg_bytes / sec / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                  "frac": None, "traffic": None, "note": "no PMC counters in this run: memory-side traffic unknown, frac withheld"})
+        return r
+    # the PMC passes ran a launch of the same shape; scale their per-launch counters to this launch by ray count
+    scale = rays_per_launch / max(1.0, pmc["rays"] / max(1, pmc["launches"]))
+    miss_bytes = pmc["TCC_MISS_sum"] * LINE_BYTES * scale
+    write_bytes = pmc["WRITE_SIZE"] * 1024.0 * scale
+    traffic = miss_bytes + write_bytes
+    hbm_gbs = traffic / sec / 1e9
+    busy = 4.0 * pmc["SQ_ACTIVE_INST_VALU"] / (pmc["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0)
+    lane = pmc["SQ_THREAD_CYCLES_VALU"] / (64.0 * pmc["SQ_ACTIVE_INST_VALU"])
+    r["hbm"] = {"achieved": round(hbm_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(hbm_gbs / HBM_PEAK_GBS, 4),
+                "frac_of_measured_copy_peak": round(hbm_gbs / HBM_MEASURED_COPY_GBS, 4),
+                "bytes_per_ray": round(traffic / rays_per_launch, 1),
+                "l2_hit_rate": round(pmc["TCC_HIT_sum"] / max(1.0, pmc["TCC_HIT_sum"] + pmc["TCC_MISS_sum"]), 4),
+                "fetch_size_x2_bytes": int(round(pmc["FETCH_SIZE"] * 1024.0 * 2.0 * scale)),
+                "note": "L2 misses x 128 B + WRITE_SIZE per launch / HIP-event launch time; Infinity Cache hits are included "
+                        "(the counters sit on the L2's memory side)"}
+    r["valu"] = {"busy_frac": round(busy, 4), "lane_use": round(lane, 4), "useful_lane_frac": round(busy * lane, 4),
+                 "note": "busy = 4 x SQ_ACTIVE_INST_VALU / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs); lane use = SQ_THREAD_CYCLES_VALU / "
+                         "(64 x SQ_ACTIVE_INST_VALU)"}
+    r["algorithmic"]["memory_side_over_algorithmic"] = round(traffic / max(1.0, alg_bytes), 4)
+    r["traffic"] = int(round(traffic))
+    r["traffic_unit"] = "bytes per launch (TCC_MISS_sum x 128 + WRITE_SIZE)"
+    if busy >= hbm_gbs / HBM_PEAK_GBS:
+        r.update({"bound": "valu", "achieved": round(busy, 4), "peak": 1.0, "unit": "VALU busy fraction of kernel cycles",
+                  "frac": round(busy, 4)})
+    else:
+        r.update({"bound": "hbm", "achieved": round(hbm_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                  "frac": round(hbm_gbs / HBM_PEAK_GBS, 4)})
+    return r
+
+
+# ----------------------------------------------------------------------------------------------- closest hit
+def closest_hit_bench(torch, G, Scene, n_rays, with_cpu, pmc):
     from oracle.binding import OracleScene
     out = {"mesh": "icosphere L8, 1310720 triangles, radius 2.5", "rays_per_batch": n_rays}
     desc = G.scene_env_sphere(8)
@@ -63,7 +198,6 @@ def closest_hit_bench(torch, G, Scene, FLAG_COUNTERS, n_rays, with_cpu):
         d_d = torch.from_numpy(rd).cuda()
         d_p = torch.empty(n_rays, dtype=torch.int32, device="cuda")
         d_t = torch.empty(n_rays, dtype=torch.float32, device="cuda")
-        torch.cuda.synchronize()
         s.trace_closest_device(d_o.data_ptr(), d_d.data_ptr(), n_rays, d_p.data_ptr(), d_t.data_ptr())  # warm-up
         ms_ext, ms_all = [], []
         for _ in range(5):
@@ -71,24 +205,24 @@ def closest_hit_bench(torch, G, Scene, FLAG_COUNTERS, n_rays, with_cpu):
             ms_ext.append(st["ms_extend"])
             ms_all.append(st["ms_total"])
         n_cpu = min(n_rays, 1 << 20)
-        gp = d_p[:n_cpu].cpu().numpy()  # results of the timed (production) kernel, before the counting run overwrites them
+        gp = d_p[:n_cpu].cpu().numpy()  # results of the timed (production) kernel, before the counting runs overwrite them
         gt = d_t[:n_cpu].cpu().numpy()
         n_ctr = min(n_rays, 1 << 22)
         sc = s.trace_closest_device(d_o.data_ptr(), d_d.data_ptr(), n_ctr, d_p.data_ptr(), d_t.data_ptr(), counters=True)
+        sw = s.trace_closest_device(d_o.data_ptr(), d_d.data_ptr(), n_ctr, d_p.data_ptr(), d_t.data_ptr(), work_counters=True)
         hit_frac = sc["ctr_hits"] / n_ctr
         means = {k: sc["ctr_" + k] / n_ctr for k in ("nodes", "pops", "refs", "tris")}
-        bpr = bytes_per_ray(means["nodes"], means["refs"], means["tris"], hit_frac)
+        ref_bpr = bytes_per_ray(means["nodes"], means["refs"], means["tris"], hit_frac)
+        alg_bpr, per = product_bytes_per_ray(sw, n_ctr, origin_bytes=16.0, queue_bytes=0.0)
         ms = float(np.median(ms_ext))
         rec = {
             "Mrays_per_s": round(n_rays / ms / 1e3, 1),
             "Mrays_per_s_incl_ray_setup": round(n_rays / float(np.median(ms_all)) / 1e3, 1),
             "ms_extend": round(ms, 3),
-            "per_ray": {k: round(v, 2) for k, v in means.items()}, "hit_frac": round(hit_frac, 4),
+            "reference_walk_per_ray": {k: round(v, 2) for k, v in means.items()}, "hit_frac": round(hit_frac, 4),
             "culled_candidate_frac": round(sc["ctr_culled"] / max(1, sc["ctr_tris"]), 4),
-            "bytes_per_ray": round(bpr, 1),
-            "reference_layout_bytes_per_ray": round(80 * means["nodes"] + 72 * means["tris"], 1),
-            "roofline": {"bound": "hbm", "achieved": round(bpr * n_rays / (ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(bpr * n_rays / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": None},
+            "product_walk_per_ray": {k: round(v, 2) for k, v in per.items()},
+            "roofline": roofline_views(pmc.get(name) if pmc else None, ms, n_rays, alg_bpr, ref_bpr),
         }
         if orc is not None:
             t0 = time.time()
@@ -103,6 +237,41 @@ def closest_hit_bench(torch, G, Scene, FLAG_COUNTERS, n_rays, with_cpu):
     return out
 
 
+# ----------------------------------------------------------------------------------------------- launching ranks
+def launch_ranks(n, argv):
+    """`python bench.py --gpus N` outside torchrun: start N rank processes (fresh interpreters; this parent never touches
+    a GPU) and exit with the worst of their codes.  Rank 0 prints the JSON line on our stdout."""
+    import torch  # device_count() does not initialise the GPU
+    have = torch.cuda.device_count()
+    if have < n:
+        sys.stderr.write("bench.py: --gpus %d asked for, %d visible device(s): refusing to run a smaller job under that label\n" % (n, have))
+        return 3
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env))
+    worst = 0
+    try:
+        while procs:
+            for p in list(procs):
+                rc = p.poll()
+                if rc is None:
+                    continue
+                procs.remove(p)
+                if rc != 0:
+                    worst = worst or rc
+                    for q in procs:  # one rank failed: the others would wait in a collective for ever
+                        q.terminate()
+            time.sleep(0.2)
+    finally:
+        for p in procs:
+            p.kill()
+    return worst
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -115,125 +284,164 @@ def main():
     ap.add_argument("--closest-rays", type=int, default=1 << 24)
     ap.add_argument("--no-closest", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 --pmc child passes (roofline.frac is then withheld)")
+    ap.add_argument("--no-strong", action="store_true")
+    ap.add_argument("--pmc-timeout", type=float, default=150.0)
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--backend", default="nccl", help="process-group backend (nccl = RCCL)")
     args = ap.parse_args()
 
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d: launch one rank per GPU (torchrun --nproc-per-node %d)"
+                         % (args.gpus, world, args.gpus))
+
+    def log(msg):
+        if rank == 0:
+            sys.stderr.write("[bench] %s\n" % msg)
+            sys.stderr.flush()
+
+    # PMC passes first: child processes own the GPU while this one has not initialised it yet
+    pmc, pmc_source = None, "skipped (--no-pmc or N > 1)"
+    if world == 1 and not args.no_pmc:
+        pmc, pmc_source = collect_pmc(args, log)
+        if pmc is None:
+            log("PMC collection failed: " + pmc_source)
+            fallback = os.path.join(ROOT, "profiles", "r2_pmc_bench.json")
+            if os.path.exists(fallback):
+                pmc = json.load(open(fallback))["parts"]
+                pmc_source = "profiles/r2_pmc_bench.json (committed; live collection failed: %s)" % pmc_source
+
     import torch
     import torch.distributed as dist
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+    if torch.cuda.device_count() <= local_rank:
+        raise SystemExit("bench.py: rank %d has no device %d" % (rank, local_rank))
     torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(args.backend)
 
     from cuda_path_tracer_amd import generators as G
-    from cuda_path_tracer_amd._lib import FLAG_COUNTERS
-    from cuda_path_tracer_amd.parallel import rank_samples
+    from cuda_path_tracer_amd._lib import FLAG_COUNTERS, FLAG_WORK_COUNTERS
+    from cuda_path_tracer_amd.parallel import render_distributed, share_scene
     from cuda_path_tracer_amd.scene import Scene, make_config
 
     W, H, K, Wm, S = args.width, args.height, args.steps, args.warmup, args.spp_per_step
-    desc = G.scene_icosphere_room(args.level)
-    scene = desc.apply(Scene())
-    scene.commit(devices=(local_rank,))
-    spp_total = K * S * world  # normalisation constant of the timed render (kernel.cu:343)
 
-    def step(i, accum, flags=0):
-        b, e, stride = rank_samples(i * S * world, (i + 1) * S * world, rank, world)
-        cfg = make_config(W, H, spp=spp_total, cam_depth=6, light_depth=0, sample_begin=b, sample_end=e,
-                          sample_stride=stride, flags=flags)
-        return scene.render_device(cfg, accum.data_ptr())
+    def build():
+        sc = G.scene_icosphere_room(args.level).apply(Scene())
+        sc.commit(devices=())  # kd build + pack on the host, once per job
+        return sc
 
+    t_build = time.perf_counter()
+    scene = share_scene(build, Scene, rank, world, device=dev if args.backend == "nccl" else None)
+    scene.commit(devices=(local_rank,))  # packed already (built or imported): this only uploads the arena
+    t_build = time.perf_counter() - t_build
+
+    def renderer(spp_total, flags=0):
+        def render_into(b, e, stride, accum):
+            cfg = make_config(W, H, spp=spp_total, cam_depth=6, light_depth=0, sample_begin=b, sample_end=e, sample_stride=stride,
+                              flags=flags)
+            return scene.render_device(cfg, accum.data_ptr())
+        return render_into
+
+    all_reduce = dist.all_reduce if world > 1 else None
     scratch = torch.zeros(W * H * 3, dtype=torch.float32, device="cuda")
     accum = torch.zeros(W * H * 3, dtype=torch.float32, device="cuda")
-    torch.cuda.synchronize()
-    for i in range(Wm):
-        step(K + i, scratch)
-    ctr = step(K + Wm, scratch, flags=FLAG_COUNTERS)  # untimed: per-ray traversal means of this workload
-    if world > 1:
-        dist.all_reduce(scratch)  # warm the communicator
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    tot = {"rays_total": 0, "rays_extended": 0, "ms_extend": 0.0, "ms_total": 0.0, "extend_launches": 0, "samples": 0,
-           "rays_camera": 0, "rays_shadow": 0}
-    for i in range(K):
-        st = step(i, accum)
-        for k in tot:
-            tot[k] += st[k]
-    if world > 1:
-        dist.all_reduce(accum)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    spp_total = K * S * world  # normalisation constant of the timed render (kernel.cu:343)
+
+    # untimed: warm-up steps (incl. the collective), then the two counting steps of this workload on rank 0's share
+    if Wm > 0:
+        render_distributed(renderer(spp_total), scratch, 0, Wm * S * world, rank, world, all_reduce, samples_per_step=S * world)
+    ctr = render_distributed(renderer(spp_total, FLAG_COUNTERS), scratch, 0, S * world, rank, world, all_reduce)[0]
+    wrk = render_distributed(renderer(spp_total, FLAG_WORK_COUNTERS), scratch, 0, S * world, rank, world, all_reduce)[0]
+
+    def timed(total_samples, samples_per_step, target):
+        """barrier + sync | K steps + one all-reduce | sync + barrier; max over ranks."""
+        target.zero_()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        stats = render_distributed(renderer(total_samples), target, 0, total_samples, rank, world, all_reduce,
+                                   samples_per_step=samples_per_step)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt.item())
+        return dt, stats
+
+    elapsed, steps = timed(spp_total, S * world, accum)
+    assert len(steps) == K
+    tot = {k: sum(st[k] for st in steps) for k in ("rays_total", "rays_extended", "ms_extend", "ms_total", "extend_launches",
+                                                    "samples", "rays_camera", "rays_shadow", "nonfinite_samples")}
     img_mean = float(accum.mean().item())
+    strong = None
+    if world > 1 and not args.no_strong:
+        # strong scaling: the frame ONE GPU renders in the weak run (K*S spp in all), split over the ranks
+        dt, sst = timed(K * S, S, scratch)
+        strong = {"value": round(W * H * K * S / dt, 1), "unit": "pixel-samples/s", "total_spp": K * S, "steps": len(sst),
+                  "ms_total": round(dt * 1e3, 3), "scaling": "strong",
+                  "note": "fixed total work: %d spp of the %dx%d frame over %d ranks (%d spp per rank per step)" % (K * S, W, H, world, max(1, S // world))}
 
     if rank == 0:
         samples_all = W * H * S * K * world
-        # per-ray means over the rays k_extend traced (rays that miss every mesh root box are answered by the stage that
-        # generated them and never reach the kernel; they are not counted in its roofline)
         rays = max(1, ctr["rays_extended"])
         means = {k: ctr["ctr_" + k] / rays for k in ("nodes", "pops", "refs", "tris")}
-        hit_frac = ctr["ctr_hits"] / rays
-        bpr = bytes_per_ray(means["nodes"], means["refs"], means["tris"], hit_frac)
-        ext_s = tot["ms_extend"] * 1e-3
-        achieved = bpr * tot["rays_extended"] / ext_s / 1e9
+        ref_bpr = bytes_per_ray(means["nodes"], means["refs"], means["tris"], ctr["ctr_hits"] / rays)
+        # (every launch of a render goes through a queue: 4 bytes; origins are charged for every ray although primary and
+        #  direct-connection launches share theirs and read none -- an upper bound that is off by < 1 %)
+        alg_bpr, per = product_bytes_per_ray(wrk, max(1, wrk["rays_extended"]), origin_bytes=16.0, queue_bytes=4.0)
+        launches = max(1, tot["extend_launches"])
         line = {
             "metric": "samples_per_sec", "value": round(samples_all / elapsed, 1), "unit": "pixel-samples/s",
             "n_gpus": world, "steps": K, "warmup": Wm, "ms_per_step": round(elapsed / K * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "C2: box room + icosphere L%d (%d tris), simple PT depth 6, %dx%d, %d spp per GPU"
                                    % (args.level, 20 * 4 ** args.level, W, H, K * S),
-                       "spp_per_step": S, "integrator": "simple", "cam_depth": 6, "parallelism": "spp-interleave x%d + all-reduce" % world},
+                       "spp_per_step": S, "integrator": "simple", "cam_depth": 6, "parallelism": "spp-interleave x%d + all-reduce" % world,
+                       "scene_build": "rank 0 builds and packs, the arena is broadcast and imported by the others" if world > 1 else "local"},
             "rays_per_sample": round(tot["rays_total"] / max(1, tot["samples"]), 3),
+            "rays_per_sample_note": "rays the product traced; the reference bound is 12 (exact elisions: shadow rays whose "
+                                    "contribution is provably zero are not made, DESIGN.md 2 item 6)",
             "rays_through_extend_frac": round(tot["rays_extended"] / max(1, tot["rays_total"]), 4),
             "Mrays_per_s_rank0": round(tot["rays_total"] / elapsed / 1e6, 1),
             "extend_share_of_gpu_time": round(tot["ms_extend"] / max(1e-9, tot["ms_total"]), 3),
-            "image_mean": round(img_mean, 6),
-            "roofline": {"bound": "hbm", "kernel": "k_extend", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-                         "bytes_per_ray": round(bpr, 1),
-                         "reference_layout_bytes_per_ray": round(80 * means["nodes"] + 72 * means["tris"], 1),
-                         "per_ray": {k: round(v, 2) for k, v in means.items()},
-                         "launches": tot["extend_launches"],
-                         "avg_launch_ms": round(tot["ms_extend"] / max(1, tot["extend_launches"]), 4),
-                         "rays_per_launch": round(tot["rays_extended"] / max(1, tot["extend_launches"])),
-                         "Mrays_per_s_in_kernel": round(tot["rays_extended"] / ext_s / 1e6, 1)},
+            "image_mean": round(img_mean, 6), "nonfinite_samples": tot["nonfinite_samples"],
+            "scene_seconds": round(t_build, 3),
+            "roofline": roofline_views(pmc.get("c2") if pmc else None, tot["ms_extend"] / launches, tot["rays_extended"] / launches,
+                                       alg_bpr, ref_bpr,
+                                       {"launches": tot["extend_launches"], "pmc_source": pmc_source,
+                                        "reference_walk_per_ray": {k: round(v, 2) for k, v in means.items()},
+                                        "product_walk_per_ray": {k: round(v, 2) for k, v in per.items()}}),
         }
-        # HBM bytes per k_extend launch: PMC counters cannot be read inside this process, so the figure is taken from the
-        # committed summary of `scripts/pmc_bench.sh` (the same workload under separate rocprofv3 --pmc passes), if present
-        pmc_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r1_pmc_bench_c2.json")
-        if os.path.exists(pmc_path):
-            try:
-                tb = json.load(open(pmc_path))["traffic_bytes_per_launch"]
-                line["roofline"]["traffic"] = round(tb["read_raw"] + tb["write"])
-                line["roofline"]["traffic_unit"] = "bytes per launch (TCC FETCH_SIZE + WRITE_SIZE, raw)"
-                line["roofline"]["traffic_source"] = "profiles/r1_pmc_bench_c2.json"
-                line["roofline"]["algorithmic_bytes_per_launch"] = round(bpr * tot["rays_extended"] / max(1, tot["extend_launches"]))
-                pm = json.load(open(pmc_path))
-                # what actually bounds the kernel: VALU issue.  busy = 4 cycles per wave64 VALU instruction
-                # over the kernel's cycles on 1024 SIMDs (GRBM_GUI_ACTIVE is summed over the 8 XCDs)
-                line["roofline"]["valu_busy_frac"] = round(4.0 * pm["SQ_ACTIVE_INST_VALU"]["mean_per_launch"]
-                                                           / (pm["GRBM_GUI_ACTIVE"]["mean_per_launch"] / 8.0 * 1024.0), 3)
-                line["roofline"]["valu_lane_use"] = round(pm["valu_lane_utilisation"], 3)
-            except (KeyError, ValueError):
-                pass
+        if strong is not None:
+            line["strong"] = strong
         if not args.no_cpu_baseline and world == 1:
             from oracle.binding import OracleScene
-            orc = desc.apply(OracleScene(threads=cpu_threads()))
+            orc = G.scene_icosphere_room(args.level).apply(OracleScene(threads=cpu_threads()))
             orc.commit()
             pstride = 61
             n_px = (W * H + pstride - 1) // pstride
-            done, t_cpu, orays = 0, 0.0, 0
+            done, t_cpu = 0, 0.0
             octr = {"nodes": 0, "refs": 0, "tris": 0, "rays": 0}
             while t_cpu < args.cpu_seconds and done < S * K:
                 cfg = make_config(W, H, spp=spp_total, cam_depth=6, light_depth=0, sample_begin=done, sample_end=done + 1)
@@ -252,7 +460,7 @@ def main():
             }
         if not args.no_closest and world == 1:
             del scratch
-            line["closest_hit"] = closest_hit_bench(torch, G, Scene, FLAG_COUNTERS, args.closest_rays, not args.no_cpu_baseline)
+            line["closest_hit"] = closest_hit_bench(torch, G, Scene, args.closest_rays, not args.no_cpu_baseline, pmc)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

@@ -204,6 +204,7 @@ int mipt_scene_add_material(mipt_scene *s, const float kd[3], const float ks[3])
     for (int k = 0; k < 3; k++) { m.kd[k] = kd[k]; m.ks[k] = ks[k]; }
     s->host.materials.push_back(m);
     s->committed = false;
+    s->host.packed = false;  // the description changed: the next commit packs again
     return (int)s->host.materials.size() - 1;
 }
 
@@ -214,6 +215,7 @@ int mipt_scene_add_light(mipt_scene *s, const float loc[3], const float power[3]
     for (int k = 0; k < 3; k++) { l.loc[k] = loc[k]; l.power[k] = power[k]; }
     s->host.lights.push_back(l);
     s->committed = false;
+    s->host.packed = false;  // the description changed: the next commit packs again
     return (int)s->host.lights.size() - 1;
 }
 
@@ -228,6 +230,7 @@ int mipt_scene_add_plane(mipt_scene *s, const float point[3], const float normal
     p.material = material;
     s->host.planes.push_back(p);
     s->committed = false;
+    s->host.packed = false;  // the description changed: the next commit packs again
     return (int)s->host.planes.size() - 1;
 }
 
@@ -241,6 +244,7 @@ int mipt_scene_add_sphere(mipt_scene *s, const float center[3], float radius, in
     sp.material = material;
     s->host.spheres.push_back(sp);
     s->committed = false;
+    s->host.packed = false;  // the description changed: the next commit packs again
     return (int)s->host.spheres.size() - 1;
 }
 
@@ -256,6 +260,7 @@ int mipt_scene_add_mesh(mipt_scene *s, const float *pos, const float *nrm, int64
     m.nrm.assign(nrm, nrm + n_tris * 9);
     s->host.meshes.push_back(std::move(m));
     s->committed = false;
+    s->host.packed = false;  // the description changed: the next commit packs again
     return (int)s->host.meshes.size() - 1;
 }
 
@@ -270,6 +275,7 @@ int mipt_scene_add_mesh_obj(mipt_scene *s, const char *path, const float positio
     m.material = material;
     s->host.meshes.push_back(std::move(m));
     s->committed = false;
+    s->host.packed = false;  // the description changed: the next commit packs again
     return (int)s->host.meshes.size() - 1;
 }
 
@@ -289,6 +295,7 @@ int mipt_scene_set_envmap_rgbe_dir(mipt_scene *s, const char *folder) {
     }
     s->host.env = std::move(env);
     s->committed = false;
+    s->host.packed = false;  // the description changed: the next commit packs again
     return 0;
 }
 
@@ -301,6 +308,7 @@ int mipt_scene_set_envmap_f32(mipt_scene *s, const float *faces6, int w, int h) 
     env.f32.assign(faces6, faces6 + (size_t)6 * w * h * 3);
     s->host.env = std::move(env);
     s->committed = false;
+    s->host.packed = false;  // the description changed: the next commit packs again
     return 0;
 }
 
@@ -312,7 +320,8 @@ int mipt_scene_commit(mipt_scene *s, const int *device_ids, int n_devices) {
     s->devs.clear();
     s->committed = false;
     std::string err;
-    if (!s->host.imported && !s->host.pack(0, err)) return fail(-4, err);  // an imported scene is already packed
+    // (a scene that is already packed -- committed before with no edit since, or imported -- is only uploaded)
+    if (!s->host.packed && !s->host.pack(0, err)) return fail(-4, err);
     for (int i = 0; i < n_devices; i++) {
         DeviceCtx dc;
         dc.device = device_ids[i];

@@ -1,9 +1,17 @@
-"""Multi-GPU sample partitioning: one process per GPU, every rank renders the FULL frame with
-the samples s = begin + rank, begin + rank + world, ... (interleaved), the scene is replicated, and the fp32
-accumulation framebuffer is combined with ONE all-reduce (RCCL over xGMI when the backend is "nccl").
+"""Multi-GPU rendering, one process per GPU.  The reference is single-GPU (`cudaSetDevice(0)`,
+kernel.cu:377); what replaces its one D2H copy (kernel.cu:416) at N > 1 is:
 
-The RNG is keyed on (seed, pixel, sample index), so the sample set -- and therefore the image up to fp32
-summation order -- does not depend on the number of ranks."""
+  * sample partition  every rank renders the FULL frame with the samples s = begin + rank, begin + rank + world, ...
+                      (`rank_samples`); the RNG is keyed on (seed, pixel, sample index), so the sample set -- and the
+                      image up to fp32 summation order -- does not depend on the number of ranks;
+  * one collective    the fp32 accumulation framebuffers are summed by ONE all-reduce (RCCL over xGMI when the
+                      process group's backend is "nccl") at the end of `render_distributed`;
+  * one kd build      rank 0 builds and packs the scene, the packed arena travels by broadcast and the other ranks
+                      import it (`share_scene`) -- instead of `world` contended host builds of the same trees.
+
+`bench.py` and the gloo tests drive exactly these functions; the renderer is passed in as a callable so that the CPU
+test can put the oracle behind the same partition / collective logic."""
+import numpy as np
 
 
 def rank_samples(sample_begin, sample_end, rank, world):
@@ -17,13 +25,56 @@ def count_samples(begin, end, stride):
     return 0 if end <= begin else (end - begin + stride - 1) // stride
 
 
-def render_distributed(render_into, accum, sample_begin, sample_end, rank, world, all_reduce=None):
-    """render_into(begin, end, stride, accum) must ADD sum_s trace_s/spp for its samples into `accum`.
-    all_reduce(accum) sums the framebuffer over ranks in place (torch.distributed.all_reduce); None = single rank."""
-    b, e, s = rank_samples(sample_begin, sample_end, rank, world)
-    render_into(b, e, s, accum)
+def render_distributed(render_into, accum, sample_begin, sample_end, rank, world, all_reduce=None, samples_per_step=0):
+    """Renders this rank's share of the sample indices [sample_begin, sample_end) into `accum` and sums `accum` over ranks.
+
+    render_into(begin, end, stride, accum) must ADD sum_s trace_s/spp for s = begin, begin + stride, ... < end into
+    `accum` and return a stats dict (or None).  samples_per_step > 0 cuts the range into steps of that many sample
+    INDICES (all ranks together), one render_into call each; 0 renders it in one call.  all_reduce(accum) sums the
+    framebuffer over ranks in place (torch.distributed.all_reduce); None is only allowed for world == 1.
+    Returns the list of the steps' stats."""
+    if world > 1 and all_reduce is None:
+        raise ValueError("all_reduce is required when world > 1")
+    step = int(samples_per_step) if samples_per_step and samples_per_step > 0 else max(1, sample_end - sample_begin)
+    stats = []
+    for lo in range(sample_begin, sample_end, step):
+        b, e, s = rank_samples(lo, min(sample_end, lo + step), rank, world)
+        stats.append(render_into(b, e, s, accum))
     if world > 1:
-        if all_reduce is None:
-            raise ValueError("all_reduce is required when world > 1")
         all_reduce(accum)
-    return accum
+    return stats
+
+
+def broadcast_blob(blob, rank, world, device=None):
+    """Broadcasts a uint8 numpy array from rank 0 over the default torch.distributed process group (RCCL needs the
+    buffer on the GPU: pass this rank's torch device; gloo takes host tensors: device=None).  Returns the array on
+    every rank."""
+    if world == 1:
+        return blob
+    import torch
+    import torch.distributed as dist
+    size = torch.tensor([blob.size if rank == 0 else 0], dtype=torch.int64, device=device)
+    dist.broadcast(size, src=0)
+    if rank == 0:
+        buf = torch.from_numpy(np.ascontiguousarray(blob, dtype=np.uint8))
+        buf = buf.to(device) if device is not None else buf.clone()
+    else:
+        buf = torch.empty(int(size.item()), dtype=torch.uint8, device=device)
+    dist.broadcast(buf, src=0)
+    return buf.cpu().numpy()
+
+
+def share_scene(build, make_empty, rank, world, device=None):
+    """Build once, ship everywhere.  `build()` -> a scene that has been described and packed on the host
+    (`commit(devices=())`), called on rank 0 only; `make_empty()` -> an empty scene of the same class.  Returns this
+    rank's scene, packed but not yet uploaded: the caller commits it on its own device (which for an imported scene
+    only uploads)."""
+    if world == 1:
+        return build()
+    if rank == 0:
+        scene = build()
+        broadcast_blob(scene.export_blob(), rank, world, device)
+        return scene
+    scene = make_empty()
+    scene.import_blob(broadcast_blob(None, rank, world, device))
+    return scene
