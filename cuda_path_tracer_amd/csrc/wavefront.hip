@@ -472,7 +472,6 @@ __global__ __launch_bounds__(kBlock) void k_shade(DScene sc, PassParams pp, WfBu
                     const f4 lp4 = b.lv_pos[vi];
                     if (lp4.w < 0.0f) break;
                     const f3 LT = xyz(b.lv_T[vi]);
-                    if (LT.x == 0.0f && LT.y == 0.0f && LT.z == 0.0f) continue;  // Q14: contributes exactly 0
                     const f4 ln4 = b.lv_nrm[vi];
                     const f3 dir = norm3(xyz(lp4) - s.pos);
                     const float dist = len3(xyz(lp4) - s.pos);
@@ -483,6 +482,9 @@ __global__ __launch_bounds__(kBlock) void k_shade(DScene sc, PassParams pp, WfBu
                     const f3 cw = Tc * brdf * cc / pc;
                     const f3 lw = LT / ln4.w;
                     const f3 contrib = lw * G * cw;
+                    // Q14: a stored vertex whose throughput is zero adds exactly 0 and needs no ray -- unless its pdf is 0
+                    // too (SampleDiffuse returned z / pi == 0): then kernel.cu:277 is 0/0 and the NaN must be kept
+                    if (contrib.x == 0.0f && contrib.y == 0.0f && contrib.z == 0.0f) continue;
                     const size_t si = sbase + 1 + jj;
                     b.sh_o[si] = mk4(s.pos + s.nrm * kEps, 0.f);
                     b.sh_d[si] = mk4(norm3(dir), 0.f);

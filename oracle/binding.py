@@ -27,6 +27,20 @@ class OrcCounters(C.Structure):
         return {n: getattr(self, n) for n, _ in self._fields_}
 
 
+class OrcSampleProbe(C.Structure):
+    _fields_ = [("first_cause", C.c_int32), ("light_vertex", C.c_int32), ("cam_vertex", C.c_int32), ("sqrt_negative", C.c_int32),
+                ("zero_pdf_vertices", C.c_int32), ("rng_draws", C.c_int32), ("operand", C.c_float * 4)]
+
+    CAUSES = ("none", "direct: cam_throughput / cam_pdf (kernel.cu:254)", "light weight: light_throughput[j] / light_pdf[j] (kernel.cu:277)",
+              "geometry term: cosCam * cosLight / dist^2 (kernel.cu:274)", "camera weight: ... / cam_pdf (kernel.cu:276)", "product of finite factors")
+
+    def as_dict(self):
+        d = {n: getattr(self, n) for n, _ in self._fields_ if n != "operand"}
+        d["operand"] = [float(x) for x in self.operand]
+        d["cause"] = self.CAUSES[self.first_cause]
+        return d
+
+
 _lib = None
 _VP = C.c_void_p
 _F3 = C.POINTER(C.c_float)
@@ -61,6 +75,7 @@ def load():
     lib.orc_scene_commit.argtypes = [_VP, C.c_int]
     lib.orc_trace_closest.argtypes = [_VP, _VP, _VP, C.c_int64, _VP, _VP, C.POINTER(OrcCounters), C.c_int, C.c_int]
     lib.orc_render.argtypes = [_VP, C.POINTER(OrcConfig), _VP, C.POINTER(OrcCounters), C.c_int]
+    lib.orc_explain_sample.argtypes = [_VP, C.POINTER(OrcConfig), C.c_int64, C.c_int32, _F3, C.POINTER(OrcSampleProbe)]
     lib.orc_mesh_count.argtypes = [_VP]
     lib.orc_kd_sizes.argtypes = [_VP, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
     lib.orc_kd_export.argtypes = [_VP, C.c_int] + [_VP] * 7
@@ -174,6 +189,15 @@ class OracleScene:
         ctr = OrcCounters()
         _check(self._lib.orc_render(self._h, C.byref(oc), _ptr(img), C.byref(ctr), self.threads))
         return img, ctr.as_dict()
+
+    def explain_sample(self, cfg, pixel, sample):
+        """(rgb of ONE sample, not divided by spp; probe dict): which reference expression made it non-finite."""
+        oc = OrcConfig(cfg.width, cfg.height, cfg.spp, cfg.cam_depth, cfg.light_depth, cfg.use_envmap, cfg.seed,
+                       cfg.sample_begin, cfg.sample_end, max(1, cfg.sample_stride), 1)
+        rgb = (C.c_float * 3)()
+        pr = OrcSampleProbe()
+        _check(self._lib.orc_explain_sample(self._h, C.byref(oc), int(pixel), int(sample), rgb, C.byref(pr)))
+        return np.array(rgb[:], np.float32), pr.as_dict()
 
     def env_lookup(self, dirs, with_index=False):
         dirs = np.ascontiguousarray(dirs, dtype=np.float32).reshape(-1, 3)

@@ -753,6 +753,17 @@ inline float fixed_cosf(float x) {
     float y = (j == 1 || j == 2) ? trig_sin_kernel(r) : trig_cos_kernel(r);
     return sign * y;
 }
+// Diagnostic of orc_explain_sample: which operand of which reference expression made a sample non-finite.
+struct Probe {
+    int first_cause = 0;     // ORC_NF_* of the FIRST non-finite contribution added to the sample
+    int light_vertex = -1;   // j of the connection (ORC_NF_LIGHT_WEIGHT / _GEOMETRY / _CAMERA_WEIGHT)
+    int cam_vertex = -1;     // i of the camera vertex
+    int sqrt_negative = 0;   // SampleDiffuse calls whose 1 - x*x - y*y was < 0 (samplers.cuh:19: z = NaN)
+    int zero_pdf_vertices = 0;  // light vertices stored with pdf == 0 (SampleDiffuse returned z/pi == 0)
+    float operand[4] = {0, 0, 0, 0};
+};
+thread_local Probe *g_probe = nullptr;
+inline bool finite3(V3 v) { return std::isfinite(v.x) && std::isfinite(v.y) && std::isfinite(v.z); }
 // light.cuh:30-39 (Q12: not uniform on the sphere)
 inline V3 light_sample_dir(Rng &rng) {
     V3 X = mk(0, 0, 1), Y = mk(0, 1, 0), Z = mk(1, 0, 0);
@@ -772,6 +783,7 @@ inline float sample_diffuse(V3 N, V3 &out, Rng &rng) {
         y = 2.0f * rng.u() - 1.0f;
     } while (x * x + y * y > 1.0f);
     z = sqrtf(1.0f - x * x - y * y);
+    if (g_probe && (1.0f - x * x - y * y) < 0.0f) g_probe->sqrt_negative++;
     out = N * z + T * x + B * y;
     return z / PI;
 }
@@ -812,6 +824,7 @@ struct LightVertex {
     float pdf = 0.f;
 };
 
+
 // kernel.cu:173-306.  light_depth == 0 selects the build-defined "simple" integrator:
 // the camera loop :239-303 without the light sub-path and without the connection block :259-280.
 V3 trace_sample(const orc_scene &sc, const orc_render_config &cfg, Ray cam_ray, Rng &rng, Ctr &c) {
@@ -851,6 +864,7 @@ V3 trace_sample(const orc_scene &sc, const orc_render_config &cfg, Ray cam_ray, 
             if (nh.t < 0) break;
             L[i + 1].hit = nh;
             L[i + 1].pdf = L[i].pdf * pdf_b;
+            if (g_probe && L[i + 1].pdf == 0.0f) g_probe->zero_pdf_vertices++;
         }
     }
     V3 Tc = mk(1, 1, 1);
@@ -871,6 +885,11 @@ V3 trace_sample(const orc_scene &sc, const orc_render_config &cfg, Ray cam_ray, 
                 float ct = dot(hit.nrm, neg(ld));
                 if (ct > EPS) {
                     V3 brdf = m.kd / PI;
+                    if (g_probe && !g_probe->first_cause && !finite3((Tc / pc) * (lr * brdf * ct))) {
+                        g_probe->first_cause = ORC_NF_DIRECT;  // kernel.cu:254: cam_throughput / cam_pdf
+                        g_probe->cam_vertex = i;
+                        g_probe->operand[0] = Tc.x; g_probe->operand[1] = pc; g_probe->operand[2] = lr.x; g_probe->operand[3] = ct;
+                    }
                     out = out + (Tc / pc) * (lr * brdf * ct);
                 }
             }
@@ -887,6 +906,13 @@ V3 trace_sample(const orc_scene &sc, const orc_render_config &cfg, Ray cam_ray, 
             V3 brdf = m.kd / PI;
             V3 cw = Tc * brdf * cc / pc;
             V3 lw = L[j].T / L[j].pdf;
+            if (g_probe && !g_probe->first_cause && !finite3(lw * G * cw)) {
+                // kernel.cu:277 light_throughput[j] / light_pdf[j]; :274 G = cosCam cosLight / dist^2; :276 camera_weight
+                g_probe->first_cause = !finite3(lw) ? ORC_NF_LIGHT_WEIGHT : (!std::isfinite(G) ? ORC_NF_GEOMETRY : (!finite3(cw) ? ORC_NF_CAMERA_WEIGHT : ORC_NF_PRODUCT));
+                g_probe->light_vertex = j;
+                g_probe->cam_vertex = i;
+                g_probe->operand[0] = L[j].T.x; g_probe->operand[1] = L[j].pdf; g_probe->operand[2] = G; g_probe->operand[3] = cw.x;
+            }
             out = out + lw * G * cw;
         }
         float pd = average(m.kd), pm = average(m.ks);  // :283-300 (Q16)
@@ -1113,6 +1139,29 @@ int orc_render(orc_scene *s, const orc_render_config *cfg, float *out, orc_count
         total.add(c);
     }
     export_ctr(total, ctr);
+    return 0;
+}
+
+// One (pixel, sample) of orc_render with the probe armed: rgb = the sample's radiance (NOT divided by spp).
+int orc_explain_sample(orc_scene *s, const orc_render_config *cfg, int64_t pixel, int32_t sample, float rgb[3], orc_sample_probe *out) {
+    if (!s->committed || !s->cam.set || s->lights.empty()) return fail("oracle: scene not ready");
+    const int W = cfg->width, H = cfg->height;
+    if (pixel < 0 || pixel >= (int64_t)W * H) return fail("oracle: pixel out of range");
+    Probe pr;
+    Ctr c;
+    g_probe = &pr;
+    Rng rng(cfg->seed, (uint32_t)pixel, (uint32_t)sample);
+    float jx = rng.u();
+    float jy = rng.u();
+    Ray r = camera_ray(s->cam, (float)(pixel % W) + jx, (float)(pixel / W) + jy, W, H);
+    V3 L = trace_sample(*s, *cfg, r, rng, c);
+    g_probe = nullptr;
+    rgb[0] = L.x; rgb[1] = L.y; rgb[2] = L.z;
+    if (out) {
+        out->first_cause = pr.first_cause; out->light_vertex = pr.light_vertex; out->cam_vertex = pr.cam_vertex;
+        out->sqrt_negative = pr.sqrt_negative; out->zero_pdf_vertices = pr.zero_pdf_vertices; out->rng_draws = (int32_t)rng.draw;
+        for (int k = 0; k < 4; k++) out->operand[k] = pr.operand[k];
+    }
     return 0;
 }
 

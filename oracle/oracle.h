@@ -72,6 +72,25 @@ int orc_trace_closest(orc_scene *, const float *ray_o, const float *ray_d, int64
                       float *t, orc_counters *ctr, int brute, int n_threads);
 int orc_render(orc_scene *, const orc_render_config *, float *out_rgb, orc_counters *ctr, int n_threads);
 
+/* Why is this sample non-finite?  Re-traces ONE (pixel, sample) of orc_render and reports the first contribution
+ * that was not finite and which operand of the reference's expression caused it. */
+enum {
+    ORC_NF_NONE = 0,
+    ORC_NF_DIRECT = 1,        /* kernel.cu:254  (cam_throughput / cam_pdf) * (radiance * brdf * cos)           */
+    ORC_NF_LIGHT_WEIGHT = 2,  /* kernel.cu:277  light_throughput[j] / light_pdf[j]  (pdf == 0: x/0 or 0/0)     */
+    ORC_NF_GEOMETRY = 3,      /* kernel.cu:274  cosCam * cosLight / (dist * dist)                               */
+    ORC_NF_CAMERA_WEIGHT = 4, /* kernel.cu:276  cam_throughput * brdf * cosCam / cam_pdf                        */
+    ORC_NF_PRODUCT = 5        /* every factor finite, the product overflows / inf * 0                           */
+};
+typedef struct orc_sample_probe {
+    int32_t first_cause, light_vertex, cam_vertex;
+    int32_t sqrt_negative;     /* SampleDiffuse calls with 1 - x*x - y*y < 0 (samplers.cuh:19 -> z = NaN)      */
+    int32_t zero_pdf_vertices; /* light vertices stored with pdf == 0                                           */
+    int32_t rng_draws;
+    float operand[4];          /* DIRECT: Tc.x, pc, radiance.x, cos;  connections: T[j].x, pdf[j], G, cw.x       */
+} orc_sample_probe;
+int orc_explain_sample(orc_scene *, const orc_render_config *, int64_t pixel, int32_t sample, float rgb[3], orc_sample_probe *out);
+
 /* kd-tree export for structural goldens. Arrays may be NULL to query sizes only. */
 int orc_mesh_count(orc_scene *);
 int orc_kd_sizes(orc_scene *, int mesh, int64_t *n_nodes, int64_t *n_refs, int64_t *n_tris);

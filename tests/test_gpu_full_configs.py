@@ -1,0 +1,143 @@
+"""GPU: BASELINE.json's configurations at FULL size against the oracle on pixel / ray subsets it can afford, and the
+non-finite samples the reference's arithmetic produces (found by scripts/find_nonfinite.py on MI355X).
+
+Non-finite samples, named (oracle: orc_explain_sample):
+  * bidirectional (C3): `light_throughput[j] / light_pdf[j]` (kernel.cu:277) with light_pdf[j] == 0 -- SampleDiffuse
+    (samplers.cuh:19-22) drew a disc point with x*x + y*y == 1 in fp32, so z = sqrtf(0) = 0 and the pdf z/pi it returns is 0;
+    kernel.cu:230 stores pdf * 0 for every later light vertex, and every visible connection to one of them adds x/0 = inf
+    (or 0/0 = NaN for the last stored vertex, whose throughput is 0, Q14).
+  * simple + environment (C4): `sqrtf(1 - x*x - y*y)` (samplers.cuh:19) of a negative number (the disc test is on
+    x*x + y*y, the subtraction rounds the other way), z = NaN, the bounce direction is NaN, `cosTheta < epsilon` is
+    false (kernel.cu:291) so the path goes on with NaN throughput; the NaN ray misses everything and the build-defined
+    environment term adds NaN * radiance.  In a closed scene without the cube map such a path adds nothing.
+"""
+import numpy as np
+import pytest
+
+from cuda_path_tracer_amd import generators as G
+from cuda_path_tracer_amd._lib import FLAG_DROP_NONFINITE
+from cuda_path_tracer_amd.scene import Scene, make_config
+from oracle.binding import OracleScene
+
+pytestmark = pytest.mark.gpu
+
+# (sample index, pixel) of the non-finite samples of the README's bidirectional configuration, seed 0x5EED
+C3_NONFINITE = ((109, 688568), (113, 398430))
+# (sample index, pixel) in C4's frame (3840x2160, simple depth 6, cube map, synthetic 64^2 faces)
+C4_NONFINITE = ((6, 4023932), (10, 2399386))
+
+
+def _pair(desc, threads=0):
+    s = desc.apply(Scene())
+    s.commit(devices=(0,))
+    o = desc.apply(OracleScene(threads=threads))
+    o.commit()
+    return s, o
+
+
+def _same_class(a, b):
+    """Non-finite values agree as classes (NaN payloads and signs of NaN differ between x86 and gfx950)."""
+    return (np.array_equal(np.isnan(a), np.isnan(b)) and np.array_equal(np.isposinf(a), np.isposinf(b))
+            and np.array_equal(np.isneginf(a), np.isneginf(b)))
+
+
+def finite_rel_rmse(img, ref):
+    """north_star's image criterion on frames that hold non-finite pixels: rel-RMSE over the pixels finite in BOTH."""
+    ok = np.isfinite(img).all(axis=-1) & np.isfinite(ref).all(axis=-1)
+    d = (img[ok].astype(np.float64) - ref[ok].astype(np.float64))
+    return float(np.sqrt((d * d).mean()) / max(1e-30, np.sqrt((ref[ok].astype(np.float64) ** 2).mean()))), int((~ok).sum())
+
+
+def test_c3_nonfinite_samples_match_the_oracle(cube_obj):
+    s, o = _pair(G.scene_default(cube_obj))
+    for smp, pix in C3_NONFINITE:
+        cfg = make_config(1024, 1024, spp=200, cam_depth=3, light_depth=3, sample_begin=smp, sample_end=smp + 1)
+        img, st = s.render(cfg)
+        ref, _ = o.render(cfg)
+        bad = ~np.isfinite(img).all(axis=2).reshape(-1)
+        obad = ~np.isfinite(ref).all(axis=2).reshape(-1)
+        assert np.flatnonzero(bad).tolist() == [pix] and np.flatnonzero(obad).tolist() == [pix]
+        assert st["nonfinite_samples"] == 1
+        a, b = img.reshape(-1, 3), ref.reshape(-1, 3)
+        assert np.array_equal(a[~bad].view(np.uint32), b[~bad].view(np.uint32))  # every finite pixel bit for bit
+        assert _same_class(a[bad], b[bad])
+        rgb, probe = o.explain_sample(cfg, pix, smp)
+        assert probe["first_cause"] == 2 and probe["operand"][1] == 0.0 and probe["zero_pdf_vertices"] >= 1  # light_pdf[j] == 0
+        assert _same_class(rgb / np.float32(200.0), a[pix])
+        assert finite_rel_rmse(img, ref) == (0.0, 1)
+        # the opt-in deviation: the sample is dropped, the rest of the frame is untouched
+        cfg.flags = FLAG_DROP_NONFINITE
+        dropped, st2 = s.render(cfg)
+        assert np.isfinite(dropped).all() and st2["nonfinite_samples"] == 1
+        assert np.array_equal(dropped.reshape(-1, 3)[~bad].view(np.uint32), a[~bad].view(np.uint32))
+        assert (dropped.reshape(-1, 3)[pix] == 0).all()
+
+
+def test_c4_full_frame_simple_and_bidirectional_and_its_nonfinite_samples():
+    # BASELINE config C4: cube map + 1,310,720-triangle mirror-ish icosphere + floor plane (open scene), 3840x2160
+    s, o = _pair(G.scene_env_sphere(8, env_f32=G.synthetic_env_faces(64)))
+    W, H, STRIDE = 3840, 2160, 97
+    sel = np.arange(0, W * H, STRIDE)
+    for kw in (dict(cam_depth=6, light_depth=0), dict(cam_depth=3, light_depth=3)):
+        cfg = make_config(W, H, spp=1, use_envmap=True, **kw)
+        img, st = s.render(cfg)
+        ref, _ = o.render(cfg, pixel_stride=STRIDE)
+        a, b = img.reshape(-1, 3)[sel], ref.reshape(-1, 3)[sel]
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), kw
+        assert st["samples"] == W * H and (a != 0).any(axis=1).mean() > 0.3
+        if kw["light_depth"]:
+            # Q11 (kernel.cu:185): in an open scene a first light ray that escapes zeroes the whole sample
+            assert (a == 0).all(axis=1).mean() > 0.2
+    for smp, pix in C4_NONFINITE:
+        cfg = make_config(W, H, spp=1024, cam_depth=6, light_depth=0, use_envmap=True, sample_begin=smp, sample_end=smp + 1)
+        img, st = s.render(cfg)
+        bad = np.flatnonzero(~np.isfinite(img).all(axis=2).reshape(-1))
+        assert bad.tolist() == [pix] and st["nonfinite_samples"] == 1
+        rgb, probe = o.explain_sample(cfg, pix, smp)
+        assert probe["sqrt_negative"] == 1 and probe["first_cause"] == 0 and np.isnan(rgb).all()  # samplers.cuh:19
+        assert np.isnan(img.reshape(-1, 3)[pix]).all()
+        ref, _ = o.render(cfg, pixel_stride=STRIDE)
+        assert np.array_equal(img.reshape(-1, 3)[sel].view(np.uint32), ref.reshape(-1, 3)[sel].view(np.uint32))
+        # without the cube map the same NaN path adds nothing (the NaN ray misses, kernel.cu:241)
+        cfg.use_envmap = 0
+        assert np.isfinite(s.render(cfg)[0]).all()
+
+
+def test_c2_full_frame_four_samples_on_21k_pixels():
+    # BASELINE config C2 (the bench workload) at 1920x1080: 4 spp, every 97th pixel (21,378 pixels) bit-exact
+    s, o = _pair(G.scene_icosphere_room(6))
+    cfg = make_config(1920, 1080, spp=4, cam_depth=6)
+    img, st = s.render(cfg)
+    ref, _ = o.render(cfg, pixel_stride=97)
+    sel = np.arange(0, 1920 * 1080, 97)
+    assert len(sel) > 20000
+    assert np.array_equal(img.reshape(-1, 3)[sel].view(np.uint32), ref.reshape(-1, 3)[sel].view(np.uint32))
+    assert st["samples"] == 4 * 1920 * 1080 and np.isfinite(img).all() and st["nonfinite_samples"] == 0
+    # the same samples rendered in four passes, and as four interleaved sample ranges (the multi-GPU partition)
+    cfg1 = make_config(1920, 1080, spp=4, cam_depth=6, samples_per_pass=1)
+    assert np.array_equal(s.render(cfg1)[0].view(np.uint32), img.view(np.uint32))
+
+
+def test_c5_closest_hit_against_the_oracle_on_the_10m_triangle_scene():
+    # BASELINE config C5's scene (8 overlapping 1,310,720-triangle icospheres): 2^16 rays, production AND counting
+    # kernel against the oracle (mesh ordering, distance pruning with its repeat path, cull boxes, candidate spheres)
+    desc = G.scene_multi_sphere(8)
+    s, o = _pair(desc, threads=16)
+    ro, rd = G.incoherent_rays(1 << 15, (-4.6,) * 3, (4.6,) * 3)
+    co, cd = G.camera_rays(desc.camera, 256, 128, 1 << 15)
+    ro, rd = np.concatenate([ro, co]), np.concatenate([rd, cd])
+    op, ot, oc = o.trace_closest(ro, rd)
+    for counters in (False, True):
+        prim, t, st = s.trace_closest(ro, rd, counters=counters)
+        assert np.array_equal(prim, op) and np.array_equal(t.view(np.uint32), ot.view(np.uint32)), counters
+        if counters:
+            for k in ("nodes", "pops", "refs", "tris", "hits"):
+                assert st["ctr_" + k] == oc[k], k
+    tri = (op >= 0) & (op < 8 * 1310720)
+    assert tri.mean() > 0.5 and len(np.unique(op[tri] // 1310720)) == 8
+    # one bidirectional 5+5 frame slice of C5 (every 53rd pixel of 640x360, 1 spp) bit-exact as well
+    cfg = make_config(640, 360, spp=1, cam_depth=5, light_depth=5)
+    img, _ = s.render(cfg)
+    ref, _ = o.render(cfg, pixel_stride=53)
+    sel = np.arange(0, 640 * 360, 53)
+    assert np.array_equal(img.reshape(-1, 3)[sel].view(np.uint32), ref.reshape(-1, 3)[sel].view(np.uint32))
