@@ -570,6 +570,18 @@ int mipt_env_lookup(mipt_scene *s, const float *dirs, int64_t n, float *rgb) {
     return 0;
 }
 
+int mipt_hdr_load_rgbe(const char *path, int32_t *w, int32_t *h, uint32_t *texels) {
+    if (!path || !w || !h) return fail(-1, "bad argument");
+    std::vector<uint32_t> tex;
+    std::string err;
+    int ww = 0, hh = 0;
+    if (!load_hdr_rgbe(path, ww, hh, tex, err)) return fail(-3, err);
+    *w = ww;
+    *h = hh;
+    if (texels) memcpy(texels, tex.data(), tex.size() * sizeof(uint32_t));
+    return 0;
+}
+
 int mipt_mesh_count(mipt_scene *s) { return s ? (int)s->host.meshes.size() : fail(-1, "null scene"); }
 
 int mipt_kd_sizes(mipt_scene *s, int mesh, int64_t *nn, int64_t *nr, int64_t *nt) {

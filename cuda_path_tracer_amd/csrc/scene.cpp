@@ -3,9 +3,7 @@
 //
 // Reference behaviour restated here (paths relative to /root/reference/cuda-path-tracer/):
 //   Camera::set                camera.cuh:9-16
-//   SRTmtx / mat4 / vec4       math/math.cuh:50-158, math/math.cu:3-39  (row vectors; vec4(vec3,w) swaps y/z)
-//   readObjIntoMesh            shapes/mesh.cu:232-317
-//   HDRLoader::load (+RLE)     HDRLoader/HDRLoader.cu:29-191   (kept as raw RGBE texels, decoded in-kernel)
+//   (OBJ / SRT and Radiance RGBE readers: assets.cpp)
 //   copyToDevice call sites    copyToDevice/copyToDevice.h:8-55 -> ONE arena, uploaded by api.hip
 #include "scene_host.h"
 
@@ -46,248 +44,6 @@ void camera_set(HostScene &s, const float eye[3], const float lookat[3], const f
     float *dst[4] = {s.cam_eye, s.cam_lookat, s.cam_right, s.cam_up};
     for (int i = 0; i < 4; i++) { dst[i][0] = v[i].x; dst[i][1] = v[i].y; dst[i][2] = v[i].z; }
     s.cam_set = true;
-}
-
-// ------------------------------------------------------------------------------------------ OBJ
-namespace {
-struct Row4 { float c[4]; };
-struct Mat44 { Row4 r[4]; };
-
-Row4 row_times(const Row4 &v, const Mat44 &m) {  // row-vector * matrix: v0*row0 + v1*row1 + v2*row2 + v3*row3
-    Row4 acc;
-    for (int j = 0; j < 4; j++) acc.c[j] = m.r[0].c[j] * v.c[0];
-    for (int i = 1; i < 4; i++)
-        for (int j = 0; j < 4; j++) acc.c[j] = acc.c[j] + m.r[i].c[j] * v.c[i];
-    return acc;
-}
-Mat44 mat_mul(const Mat44 &a, const Mat44 &b) {
-    Mat44 o;
-    for (int i = 0; i < 4; i++) o.r[i] = row_times(a.r[i], b);
-    return o;
-}
-Mat44 identity() {
-    Mat44 m;
-    for (int i = 0; i < 4; i++)
-        for (int j = 0; j < 4; j++) m.r[i].c[j] = (i == j) ? 1.0f : 0.0f;
-    return m;
-}
-Mat44 rotation(float angle, f3 w) {
-    const float c = cosf(angle), s = sinf(angle);
-    w = norm3(w);
-    Mat44 m = identity();
-    m.r[0] = Row4{{c * (1.0f - w.x * w.x) + w.x * w.x, w.x * w.y * (1.0f - c) + w.z * s, w.x * w.z * (1.0f - c) - w.y * s, 0.0f}};
-    m.r[1] = Row4{{w.x * w.y * (1.0f - c) - w.z * s, c * (1.0f - w.y * w.y) + w.y * w.y, w.y * w.z * (1.0f - c) + w.x * s, 0.0f}};
-    m.r[2] = Row4{{w.x * w.z * (1.0f - c) + w.y * s, w.y * w.z * (1.0f - c) - w.x * s, c * (1.0f - w.z * w.z) + w.z * w.z, 0.0f}};
-    return m;
-}
-Mat44 srt(const float scale[3], const float rot[3], const float tr[3]) {
-    Mat44 S = identity(), T = identity();
-    S.r[0].c[0] = scale[0]; S.r[1].c[1] = scale[1]; S.r[2].c[2] = scale[2];
-    T.r[3].c[0] = tr[0]; T.r[3].c[1] = tr[1]; T.r[3].c[2] = tr[2];
-    Mat44 m = mat_mul(S, rotation(rot[0], mk3(1, 0, 0)));
-    m = mat_mul(m, rotation(rot[1], mk3(0, 1, 0)));
-    m = mat_mul(m, rotation(rot[2], mk3(0, 0, 1)));
-    return mat_mul(m, T);
-}
-// inverse().transpose() exactly as math.cu:3-39 + math.cuh:104-112 define them
-Mat44 normal_matrix(const Mat44 &m) {
-    const f3 a = mk3(m.r[0].c[0], m.r[0].c[1], m.r[0].c[2]), b = mk3(m.r[1].c[0], m.r[1].c[1], m.r[1].c[2]),
-             c = mk3(m.r[2].c[0], m.r[2].c[1], m.r[2].c[2]), t = mk3(m.r[3].c[0], m.r[3].c[1], m.r[3].c[2]);
-    const float det = dot3(cross3(a, b), c);
-    Mat44 inv = identity();
-    if (!(fabsf(det) < kEps)) {
-        const float id = 1.0f / det;
-        const f3 r0 = cross3(b, c) * id, r1 = cross3(c, a) * id, r2 = cross3(a, b) * id;
-        inv.r[0] = Row4{{r0.x, r0.y, r0.z, 0.0f}};
-        inv.r[1] = Row4{{r1.x, r1.y, r1.z, 0.0f}};
-        inv.r[2] = Row4{{r2.x, r2.y, r2.z, 0.0f}};
-        inv.r[3] = Row4{{-dot3(r0, t), -dot3(r1, t), -dot3(r2, t), 1.0f}};
-    }
-    Mat44 tr;
-    for (int i = 0; i < 4; i++)
-        for (int j = 0; j < 4; j++) tr.r[i].c[j] = inv.r[j].c[i];
-    return tr;
-}
-
-bool read_file(const char *path, std::vector<char> &buf) {
-    FILE *f = fopen(path, "rb");
-    if (!f) return false;
-    fseek(f, 0, SEEK_END);
-    long n = ftell(f);
-    fseek(f, 0, SEEK_SET);
-    buf.resize((size_t)std::max(0L, n) + 1);
-    size_t got = n > 0 ? fread(buf.data(), 1, (size_t)n, f) : 0;
-    fclose(f);
-    buf[got] = 0;
-    buf.resize(got + 1);
-    return true;
-}
-}  // namespace
-
-bool load_obj(const char *path, const float position[3], const float rotate[3], const float scale[3], HostMesh &out,
-              std::string &err) {
-    std::vector<char> buf;
-    if (!read_file(path, buf)) { err = std::string("cannot open OBJ file ") + path; return false; }
-    std::vector<float> P, N;      // raw v / vn triples
-    std::vector<int> pi, ni;      // 0-based indices, three per face
-    char *p = buf.data();
-    while (*p) {
-        char *eol = strchr(p, '\n');
-        if (eol) *eol = 0;
-        char *q = p;
-        while (*q == ' ' || *q == '\t') q++;
-        if (q[0] == 'v' && (q[1] == ' ' || q[1] == '\t')) {
-            char *e = q + 1;
-            for (int k = 0; k < 3; k++) P.push_back(strtof(e, &e));
-        } else if (q[0] == 'v' && q[1] == 'n' && (q[2] == ' ' || q[2] == '\t')) {
-            char *e = q + 2;
-            for (int k = 0; k < 3; k++) N.push_back(strtof(e, &e));
-        } else if (q[0] == 'f' && (q[1] == ' ' || q[1] == '\t')) {
-            char *e = q + 1;
-            int corners = 0;
-            for (;;) {
-                while (*e == ' ' || *e == '\t' || *e == '\r') e++;
-                if (!*e) break;
-                char *after;
-                long vi = strtol(e, &after, 10);
-                if (after == e) break;
-                long slot[3] = {vi, 0, 0};
-                int have[3] = {1, 0, 0};
-                e = after;
-                for (int k = 1; k < 3 && *e == '/'; k++) {  // p/t/n or p//n
-                    e++;
-                    long v = strtol(e, &after, 10);
-                    if (after != e) { slot[k] = v; have[k] = 1; e = after; }
-                }
-                if (!have[2]) { err = "OBJ face without normal index (normals are mandatory, mesh.cu:277-279)"; return false; }
-                pi.push_back((int)slot[0] - 1);
-                ni.push_back((int)slot[2] - 1);
-                corners++;
-            }
-            if (corners != 3) { err = "OBJ faces must be triangles"; return false; }
-        }
-        if (!eol) break;
-        p = eol + 1;
-    }
-    const int np = (int)P.size() / 3, nn = (int)N.size() / 3;
-    if (pi.empty()) { err = "OBJ has no faces"; return false; }
-    for (size_t k = 0; k < pi.size(); k++)
-        if (pi[k] < 0 || pi[k] >= np || ni[k] < 0 || ni[k] >= nn) { err = "OBJ index out of range"; return false; }
-    const Mat44 M = srt(scale, rotate, position), NM = normal_matrix(M);
-    out.n_tris = (int64_t)pi.size() / 3;
-    out.pos.resize(pi.size() * 3);
-    out.nrm.resize(pi.size() * 3);
-    for (size_t k = 0; k < pi.size(); k++) {
-        const float *v = &P[3 * (size_t)pi[k]], *n = &N[3 * (size_t)ni[k]];
-        const Row4 pv = row_times(Row4{{v[0], v[2], v[1], 1.0f}}, M);   // y/z swapped (math.cuh:55)
-        const Row4 nv = row_times(Row4{{n[0], n[2], n[1], 0.0f}}, NM);
-        const f3 nu = norm3(mk3(nv.c[0], nv.c[1], nv.c[2]));
-        out.pos[3 * k] = pv.c[0]; out.pos[3 * k + 1] = pv.c[1]; out.pos[3 * k + 2] = pv.c[2];
-        out.nrm[3 * k] = nu.x; out.nrm[3 * k + 1] = nu.y; out.nrm[3 * k + 2] = nu.z;
-    }
-    return true;
-}
-
-// ------------------------------------------------------------------------------------------ HDR (RGBE)
-namespace {
-struct ByteCursor {  // fgetc/feof/fseek semantics over a memory buffer
-    const unsigned char *p;
-    size_t n, i = 0;
-    bool eof = false;
-    int get() {
-        if (i >= n) { eof = true; return -1; }
-        return p[i++];
-    }
-    void back() { if (i > 0) i--; eof = false; }
-};
-typedef unsigned char Rgbe[4];
-
-bool old_rle(Rgbe *scan, int len, ByteCursor &c) {  // HDRLoader.cu:161-191
-    int rshift = 0, pos = 0;
-    while (len > 0) {
-        for (int k = 0; k < 4; k++) scan[pos][k] = (unsigned char)c.get();
-        if (c.eof) return false;
-        if (scan[pos][0] == 1 && scan[pos][1] == 1 && scan[pos][2] == 1) {
-            for (int i = scan[pos][3] << rshift; i > 0 && len > 0; i--) {
-                if (pos > 0) memcpy(scan[pos], scan[pos - 1], 4);
-                pos++;
-                len--;
-            }
-            rshift += 8;
-        } else {
-            pos++;
-            len--;
-            rshift = 0;
-        }
-    }
-    return true;
-}
-bool new_rle(Rgbe *scan, int len, ByteCursor &c) {  // HDRLoader.cu:118-159
-    if (len < 8 || len > 0x7fff) return old_rle(scan, len, c);
-    int i = c.get();
-    if (i != 2) {
-        c.back();
-        return old_rle(scan, len, c);
-    }
-    scan[0][1] = (unsigned char)c.get();
-    scan[0][2] = (unsigned char)c.get();
-    i = c.get();
-    if (scan[0][1] != 2 || (scan[0][2] & 128)) {
-        scan[0][0] = 2;
-        scan[0][3] = (unsigned char)i;
-        return old_rle(scan + 1, len - 1, c);
-    }
-    for (int comp = 0; comp < 4; comp++) {
-        for (int j = 0; j < len;) {
-            const int ci = c.get();
-            if (ci < 0) return false;
-            unsigned char code = (unsigned char)ci;
-            if (code > 128) {
-                code &= 127;
-                const unsigned char val = (unsigned char)c.get();
-                while (code-- && j < len) scan[j++][comp] = val;
-            } else {
-                while (code-- && j < len) scan[j++][comp] = (unsigned char)c.get();
-            }
-        }
-    }
-    return !c.eof;
-}
-}  // namespace
-
-bool load_hdr_rgbe(const char *path, int &w, int &h, std::vector<uint32_t> &texels, std::string &err) {
-    std::vector<char> buf;
-    if (!read_file(path, buf)) { err = std::string("cannot open HDR file ") + path; return false; }
-    ByteCursor c{reinterpret_cast<const unsigned char *>(buf.data()), buf.size() - 1};
-    if (c.n < 11 || memcmp(c.p, "#?RADIANCE", 10)) { err = std::string("not a Radiance file: ") + path; return false; }
-    c.i = 11;  // magic + one byte (HDRLoader.cu:39-45)
-    int ch = 0, old;
-    for (;;) {  // header commands end with an empty line (:50-56)
-        old = ch;
-        ch = c.get();
-        if (ch < 0) { err = "truncated HDR header"; return false; }
-        if (ch == 0xa && old == 0xa) break;
-    }
-    char reso[200];
-    int k = 0;
-    for (;;) {
-        ch = c.get();
-        if (ch < 0 || k >= 199) { err = "bad HDR resolution line"; return false; }
-        reso[k++] = (char)ch;
-        if (ch == 0xa) break;
-    }
-    reso[k] = 0;
-    if (sscanf(reso, "-Y %d +X %d", &h, &w) != 2 || w <= 0 || h <= 0) { err = "unsupported HDR orientation"; return false; }
-    texels.assign((size_t)w * h, 0u);
-    std::vector<unsigned char> line((size_t)w * 4);
-    Rgbe *scan = reinterpret_cast<Rgbe *>(line.data());
-    for (int y = 0; y < h; y++) {  // rows stay in file order: top row first (:86-91)
-        if (!new_rle(scan, w, c)) break;
-        uint32_t *dst = texels.data() + (size_t)y * w;
-        for (int x = 0; x < w; x++)
-            dst[x] = (uint32_t)scan[x][0] | ((uint32_t)scan[x][1] << 8) | ((uint32_t)scan[x][2] << 16) | ((uint32_t)scan[x][3] << 24);
-    }
-    return true;
 }
 
 // ------------------------------------------------------------------------------------------ packing

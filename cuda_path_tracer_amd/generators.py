@@ -43,6 +43,26 @@ def write_cube_obj(path):
     return path
 
 
+def write_icosphere_obj(path, level, radius=1.0, center=(0.0, 0.0, 0.0), form="p//n", eol="\n"):
+    """Indexed icosphere as an OBJ file (`v`, `vn`, `f` in the `p//n` or `p/t/n` form).  Coordinates are written with 9
+    significant digits, so the fp32 values of `icosphere()` come back bit for bit.  readObjIntoMesh swaps y and z
+    (math.cuh:55): the mesh a scene gets from this file is `icosphere(...)` with the y and z columns exchanged."""
+    V, F = icosphere_indexed(level)
+    P = (V * radius + np.asarray(center, np.float64)).astype(np.float32)
+    N = V.astype(np.float32)
+    idx = F + 1
+    with open(path, "w", newline="") as f:
+        f.write("# icosphere level %d: %d vertices, %d faces%s" % (level, len(V), len(F), eol))
+        np.savetxt(f, P, fmt="v %.9g %.9g %.9g", newline=eol)
+        np.savetxt(f, N, fmt="vn %.9g %.9g %.9g", newline=eol)
+        if form == "p/t/n":
+            f.write("vt 0.5 0.5" + eol)
+            np.savetxt(f, np.stack([idx[:, 0], idx[:, 0], idx[:, 1], idx[:, 1], idx[:, 2], idx[:, 2]], 1), fmt="f %d/1/%d %d/1/%d %d/1/%d", newline=eol)
+        else:
+            np.savetxt(f, np.stack([idx[:, 0], idx[:, 0], idx[:, 1], idx[:, 1], idx[:, 2], idx[:, 2]], 1), fmt="f %d//%d %d//%d %d//%d", newline=eol)
+    return path
+
+
 def cube_mesh(center=(0, 0, 0), half=1.0):
     P, N, tris = cube_indexed()
     pos = np.array([[P[pi] for pi, _ in t] for t in tris], dtype=np.float32) * np.float32(half) + np.asarray(center, np.float32)
@@ -50,9 +70,8 @@ def cube_mesh(center=(0, 0, 0), half=1.0):
     return pos, nrm
 
 
-def icosphere(level, radius=1.0, center=(0.0, 0.0, 0.0)):
-    """Icosphere with 20*4**level triangles; smooth normals = normalised (position - center).
-    Returns de-indexed (pos, nrm) float32 arrays of shape (n_tris, 3, 3)."""
+def icosphere_indexed(level):
+    """Unit icosphere as (V float64 (n_verts, 3), F int64 (20*4**level, 3)); 10*4**level + 2 vertices."""
     t = (1.0 + math.sqrt(5.0)) / 2.0
     V = np.array([[-1, t, 0], [1, t, 0], [-1, -t, 0], [1, -t, 0], [0, -1, t], [0, 1, t], [0, -1, -t], [0, 1, -t],
                   [t, 0, -1], [t, 0, 1], [-t, 0, -1], [-t, 0, 1]], dtype=np.float64)
@@ -75,6 +94,13 @@ def icosphere(level, radius=1.0, center=(0.0, 0.0, 0.0)):
         F = np.concatenate([
             np.stack([F[:, 0], m01, m20], 1), np.stack([F[:, 1], m12, m01], 1),
             np.stack([F[:, 2], m20, m12], 1), np.stack([m01, m12, m20], 1)], axis=0)
+    return V, F
+
+
+def icosphere(level, radius=1.0, center=(0.0, 0.0, 0.0)):
+    """Icosphere with 20*4**level triangles; smooth normals = normalised (position - center).
+    Returns de-indexed (pos, nrm) float32 arrays of shape (n_tris, 3, 3)."""
+    V, F = icosphere_indexed(level)
     nrm = V[F].astype(np.float32)
     pos = (V[F] * radius + np.asarray(center, np.float64)).astype(np.float32)
     return np.ascontiguousarray(pos), np.ascontiguousarray(nrm)

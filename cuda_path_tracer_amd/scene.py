@@ -34,6 +34,16 @@ def make_config(width, height, spp, cam_depth=6, light_depth=0, use_envmap=False
                         int(sample_stride), int(samples_per_pass), int(flags))
 
 
+def load_hdr_rgbe(path):
+    """HDRLoader::load (HDRLoader.cu:29): one Radiance file -> packed RGBE texels, uint8 array (h, w, 4), file row order."""
+    lib = _lib.load()
+    w, h = C.c_int32(), C.c_int32()
+    check(lib.mipt_hdr_load_rgbe(str(path).encode(), C.byref(w), C.byref(h), None))
+    tex = np.empty((h.value, w.value), dtype=np.uint32)
+    check(lib.mipt_hdr_load_rgbe(str(path).encode(), C.byref(w), C.byref(h), _ptr(tex)))
+    return tex.view(np.uint8).reshape(h.value, w.value, 4)
+
+
 class Scene:
     """One `Scene scene;` of the reference (kernel.cu:383), backed by libmipt."""
 

@@ -129,6 +129,12 @@ int  mipt_trace_closest_device_noalloc(mipt_scene *, int dev_slot, const float *
 /* EnvMap::getPixelColor envMap.cuh:50-89 evaluated on the device for n directions (host buffers). */
 int  mipt_env_lookup(mipt_scene *, const float *dirs, int64_t n, float *rgb);
 
+/* HDRLoader::load (HDRLoader/HDRLoader.cu:29-97) as a host-side service: decodes one Radiance .hdr file (adaptive RLE or flat
+ * scanlines, `-Y h +X w`) to packed texels R | G<<8 | B<<16 | E<<24, rows in file order (top row first); fp32 value of a
+ * component = val/256 * 2^(E-128) (convertComponent, :99-104; done in-kernel by the renderer).  texels == NULL: only w, h.
+ * Unlike the reference, a truncated file, a run that leaves its scanline or a wrong scanline width is an error. */
+int  mipt_hdr_load_rgbe(const char *path, int32_t *w, int32_t *h, uint32_t *texels /* w*h or NULL */);
+
 /* ---- introspection of the packed scene (host side; valid after commit) ---------------- */
 int  mipt_mesh_count(mipt_scene *);
 int  mipt_kd_sizes(mipt_scene *, int mesh, int64_t *n_nodes, int64_t *n_refs, int64_t *n_tris);

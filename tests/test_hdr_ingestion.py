@@ -1,0 +1,86 @@
+"""CPU (host side of libmipt): the Radiance RGBE reader (HDRLoader::load, HDRLoader.cu:29-191, restated by
+csrc/assets.cpp::RadianceReader) on well-formed files of both scanline encodings -- against the writer's texels and
+against the oracle's reader -- and on malformed ones, which are errors here (the reference keeps a half-black face)."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+from cuda_path_tracer_amd import generators as G
+from cuda_path_tracer_amd._lib import MiptError
+from cuda_path_tracer_amd.scene import load_hdr_rgbe
+from oracle import binding as B
+from tests.hdr_util import decode_rgbe, random_rgbe, write_hdr
+
+HEAD = b"#?RADIANCE\nFORMAT=32-bit_rle_rgbe\n\n"
+
+
+@pytest.mark.parametrize("w,h,rle", [(16, 9, True), (16, 9, False), (7, 5, True), (300, 4, True), (1024, 3, True), (8, 1, True)])
+def test_round_trip_and_oracle_agreement(tmp_path, w, h, rle):
+    rgbe = random_rgbe(h, w, seed=w + h)
+    p = str(tmp_path / "f.hdr")
+    write_hdr(p, rgbe, rle=rle and w >= 8)
+    got = load_hdr_rgbe(p)
+    assert got.shape == (h, w, 4) and np.array_equal(got, rgbe)
+    assert np.array_equal(decode_rgbe(got), B.hdr_load(p))   # the oracle's reader (fp32 triplets) sees the same picture
+
+
+def test_flat_scanlines_with_repeat_markers(tmp_path):
+    # old-style run: texel, then (1,1,1,n) repeats the previous texel n times; two markers in a row: n1 + (n2 << 8)
+    w = 300
+    row = bytes([10, 20, 30, 128]) + bytes([1, 1, 1, 43]) + bytes([1, 1, 1, 1]) + bytes([9, 8, 7, 120])  # 1 + 43 + 256 = 300 -> last texel never fits
+    p = tmp_path / "r.hdr"
+    p.write_bytes(HEAD + b"-Y 1 +X %d\n" % w + row[:12])
+    got = load_hdr_rgbe(str(p))
+    assert got.shape == (1, 300, 4) and (got == np.array([10, 20, 30, 128], np.uint8)).all()
+    # a scanline that starts with 2 but is not a run-length header is flat data (HDRLoader.cu:141-146)
+    flat = np.zeros((1, 8, 4), np.uint8)
+    flat[0, :, :] = [2, 7, 200, 130]
+    p.write_bytes(HEAD + b"-Y 1 +X 8\n" + flat.tobytes())
+    assert np.array_equal(load_hdr_rgbe(str(p)), flat)
+
+
+def _rle_row(w, comps):
+    return bytes([2, 2, w >> 8, w & 255]) + b"".join(comps)
+
+
+@pytest.mark.parametrize("payload,why", [
+    (b"#?RGBE\n\n-Y 1 +X 8\n", "signature"),
+    (b"#?RADIANCE\nFORMAT=x\n", "truncated header"),
+    (HEAD + b"+X 8 -Y 8\n", "orientation"),
+    (HEAD + b"-Y 0 +X 8\n", "range"),
+    (HEAD + b"-Y 1 +X 40000\n", "range"),
+    (HEAD + b"-Y 2 +X 8\n" + bytes(32), "truncated scanline"),                                   # second flat row missing
+    (HEAD + b"-Y 1 +X 8\n" + bytes([1, 1, 1, 4]) + bytes(28), "repeat marker before"),
+    (HEAD + b"-Y 1 +X 8\n" + bytes([5, 5, 5, 128, 1, 1, 1, 9]), "repeat leaves"),
+    (HEAD + b"-Y 1 +X 8\n" + _rle_row(9, [bytes([128 + 9, 0])] * 4), "different width"),
+    (HEAD + b"-Y 1 +X 8\n" + _rle_row(8, [bytes([128 + 9, 0])] * 4), "run leaves"),
+    (HEAD + b"-Y 1 +X 8\n" + _rle_row(8, [bytes([9]) + bytes(9)] * 4), "literal block leaves"),
+    (HEAD + b"-Y 1 +X 8\n" + _rle_row(8, [bytes([0])]), "zero-length"),
+    (HEAD + b"-Y 1 +X 8\n" + _rle_row(8, [bytes([128 + 8, 1])] * 3), "truncated run-length"),  # E component missing
+    (HEAD + b"-Y 1 +X 8\n" + _rle_row(8, [bytes([128 + 8, 1])] * 3 + [bytes([128 + 8])]), "truncated run-length"),
+])
+def test_malformed_files_are_errors(tmp_path, payload, why):
+    p = tmp_path / "bad.hdr"
+    p.write_bytes(payload)
+    with pytest.raises(MiptError, match=why):
+        load_hdr_rgbe(str(p))
+
+
+def test_missing_file(tmp_path):
+    with pytest.raises(MiptError, match="cannot open HDR"):
+        load_hdr_rgbe(str(tmp_path / "none.hdr"))
+
+
+@pytest.mark.skipif(G.reference_env_dir() is None, reason="reference checkout not mounted (GPU box)")
+def test_the_six_shipped_cube_faces_decode_to_the_pinned_pictures():
+    """The reference's own data files (resources/hdr-env-cube/*.hdr, 1024^2, adaptive RLE), read as data by the PRODUCT's
+    reader: the decoded fp32 pictures carry the checksums pinned in tests/golden/kd_and_assets.json (made with the
+    oracle's reader), i.e. both restatements of HDRLoader::load agree on every texel of every shipped face."""
+    meta = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "kd_and_assets.json")))
+    for f, want in meta["hdr_faces"].items():
+        rgbe = load_hdr_rgbe(G.reference_env_dir() + f + ".hdr")
+        assert list(rgbe.shape) == [1024, 1024, 4]
+        assert hashlib.sha256(decode_rgbe(rgbe).tobytes()).hexdigest() == want["sha256"], f
