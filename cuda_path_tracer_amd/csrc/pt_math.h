@@ -32,6 +32,12 @@ PT_HD float dot3(f3 a, f3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
 PT_HD f3 cross3(f3 a, f3 b) { return mk3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
 PT_HD float len3(f3 a) { return sqrtf(a.x * a.x + a.y * a.y + a.z * a.z); }
 PT_HD f3 norm3(f3 a) { return a * (1 / (len3(a) + kEps)); }
+// The point at parameter t of a ray: `ray.start + ray.dir * t` (mesh.cuh:59,90,153-162, plane.cuh:25, sphere.cuh:32) with
+// ONE rounding per component, i.e. the fused multiply-add nvcc's default (-fmad=true) makes of a product that feeds a
+// sum.  This is the one contraction of the reference's build that its published pictures show (deviation 7):
+// it decides how often a hit on a min-X box face passes `minX <= position.x` (Q5, no epsilon).  Nothing else is fused.
+PT_HD float fma_at(float o, float d, float t) { return __builtin_fmaf(d, t, o); }
+PT_HD f3 ray_at(f3 o, f3 d, float t) { return mk3(fma_at(o.x, d.x, t), fma_at(o.y, d.y, t), fma_at(o.z, d.z, t)); }
 PT_HD float avg3(f3 a) { return (a.x + a.y + a.z) / 3.0f; }
 
 // sinf/cosf of Light::randomSampleRay (light.cuh:35-38) for arguments in [0, 2*pi].  Every libm (CUDA's,

@@ -72,7 +72,7 @@ struct Surface {
 // Resolve a HitRec into position / normal / material (what the reference's Hit carries, hit.cuh:9-15).
 PT_HD Surface surface_at(const DScene &sc, f3 o, f3 d, float t, int prim) {
     Surface s;
-    s.pos = o + d * t;
+    s.pos = ray_at(o, d, t);
     int mat;
     if (prim < sc.total_tris) {
         const f4 pa = sc.tri_pos[3 * (size_t)prim], pb = sc.tri_pos[3 * (size_t)prim + 1], pc = sc.tri_pos[3 * (size_t)prim + 2];

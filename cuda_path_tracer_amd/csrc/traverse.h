@@ -96,7 +96,7 @@ PT_HD float slab_hit(const SlabBox &b, f3 o, f3 d) {
 #pragma unroll
     for (int k = 0; k < 3; k++) {
         const float t0 = b.tlo[k], t1 = b.thi[k];
-        const f3 p0 = o + d * t0, p1 = o + d * t1;
+        const f3 p0 = ray_at(o, d, t0), p1 = ray_at(o, d, t1);
         const bool ok0 = (t0 > 0.0f) & point_in_box(p0, b.lo[0], b.hi[0], b.lo[1], b.hi[1], b.lo[2], b.hi[2]);
         const bool ok1 = (t1 > 0.0f) & point_in_box(p1, b.lo[0], b.hi[0], b.lo[1], b.hi[1], b.lo[2], b.hi[2]);
         const float c0 = ok0 ? t0 : inf, c1 = ok1 ? t1 : inf;
@@ -128,14 +128,14 @@ PT_HD float plane_candidate(f4 pl, f3 o, f3 d, const SlabBox &box, float best) {
     const float t = -(dot3(N, o) + pl.w) / nd;
     if (!(t > 0.0f)) return -1.0f;                 // t<0 -> raw negative, t==0 -> fails "hit.t > 0"
     if (!(best < 0.0f || t < best)) return -1.0f;  // cannot replace the current best
-    const f3 P = o + d * t;
+    const f3 P = ray_at(o, d, t);
     if (!point_in_box(P, box.lo[0], box.hi[0], box.lo[1], box.hi[1], box.lo[2], box.hi[2])) return -1.0f;
     return t;
 }
 // Part 2: the three inside-outside edge tests (mesh.cuh:61-88) for a surviving candidate.
 PT_HD bool inside_triangle(f4 pl, f3 a, f3 b, f3 c, f3 o, f3 d, float t) {
     const f3 N = mk3(pl.x, pl.y, pl.z);
-    const f3 P = o + d * t;
+    const f3 P = ray_at(o, d, t);
     f3 C = cross3(b - a, P - a);
     if (dot3(N, C) < 0.0f) return false;
     C = cross3(c - b, P - b);
@@ -208,7 +208,7 @@ PT_HD bool descend_to_leaf(const DScene &sc, f3 o, f3 d, SlabBox &cur, int &node
 //       valid_child(j) = valid_parent(j)  AND  (the point passes the new bound),
 // because the replaced parent bound is implied by the tighter child bound (fp add is monotonic; the packer flags the
 // rare node whose split lies outside [lo, hi] with kRecheckBit and the children of such a node are re-evaluated in
-// full).  The new bound only involves the point's coordinate ALONG THE SPLIT AXIS: one mul + add per plane instead of
+// full).  The new bound only involves the point's coordinate ALONG THE SPLIT AXIS: one fused multiply-add per plane instead of
 // the whole point, one compare instead of six.  Only the split plane's own point is evaluated in full.
 // A plane that is not valid never becomes valid further down, so its t is never needed again: the slab state of the
 // fast path stores +inf in its place ("masked" t), and Box::intersect is a plain minimum.  (For a masked entry the
@@ -218,7 +218,7 @@ PT_HD void mask_slab(SlabBox &b, f3 o, f3 d) {
 #pragma unroll
     for (int k = 0; k < 3; k++) {
         const float t0 = b.tlo[k], t1 = b.thi[k];
-        const f3 p0 = o + d * t0, p1 = o + d * t1;
+        const f3 p0 = ray_at(o, d, t0), p1 = ray_at(o, d, t1);
         const bool ok0 = (t0 > 0.0f) & point_in_box(p0, b.lo[0], b.hi[0], b.lo[1], b.hi[1], b.lo[2], b.hi[2]);
         const bool ok1 = (t1 > 0.0f) & point_in_box(p1, b.lo[0], b.hi[0], b.lo[1], b.hi[1], b.lo[2], b.hi[2]);
         b.tlo[k] = ok0 ? t0 : inf;
@@ -311,14 +311,14 @@ PT_HD bool descend_fast(const DScene &sc, f3 o, f3 d, SlabBox &cur, int &node, K
         float l_lo[3], l_hi[3], r_lo[3], r_hi[3];
 #pragma unroll
         for (int k = 0; k < 3; k++) {
-            const float p0 = oa + da * cur.tlo[k], p1 = oa + da * cur.thi[k];
+            const float p0 = fma_at(oa, da, cur.tlo[k]), p1 = fma_at(oa, da, cur.thi[k]);
             l_lo[k] = (p0 <= s_eps) ? cur.tlo[k] : inf;
             l_hi[k] = (p1 <= s_eps) ? cur.thi[k] : inf;
             r_lo[k] = (s <= p0 + e_ax) ? cur.tlo[k] : inf;
             r_hi[k] = (s <= p1 + e_ax) ? cur.thi[k] : inf;
         }
         // the split plane's own point against the parent's bounds, then the one bound each child replaces
-        const f3 P = o + d * ts;
+        const f3 P = ray_at(o, d, ts);
         const float Pc[3] = {P.x, P.y, P.z};
         bool in_lo[3], in_hi[3];
         in_lo[0] = cur.lo[0] <= Pc[0];
@@ -605,7 +605,7 @@ PT_HD bool misses_every_mesh(const DScene &sc, f3 o, f3 d) {
 // it was aimed at?  target.w == 0: ray cast from the light at a surface point (kernel.cu:249); else: connection ray
 // from a camera vertex to a light vertex (kernel.cu:268).  One definition for every stage that resolves a shadow ray.
 PT_HD bool shadow_visible(f3 o, f3 d, float t, f4 target) {
-    const f3 P = o + d * t;
+    const f3 P = ray_at(o, d, t);
     const float dist = len3(P - mk3(target.x, target.y, target.z));
     if (target.w == 0.0f) return (t > 0.0f) && (dist < kEps);
     return !((t < 0.0f) || (dist > kEps));

@@ -6,6 +6,7 @@ import numpy as np
 import pytest
 
 from cuda_path_tracer_amd import generators as G
+from cuda_path_tracer_amd._lib import FLAG_DROP_NONFINITE
 from cuda_path_tracer_amd.scene import Scene, make_config
 from oracle.binding import OracleScene
 from tests.hdr_util import decode_rgbe, random_rgbe, write_hdr
@@ -143,10 +144,22 @@ def test_full_size_10m_triangle_multi_mesh(monkeypatch):
 
 @pytest.mark.parametrize("key", ["simple_d6_200spp", "bidir_3_3_200spp"])
 def test_readme_configurations_against_the_reference_renders(key, cube_obj):
-    # the README's own configurations (1024x1024, 200 samples; BASELINE config C3 is the bidirectional one) through the
-    # HIP path, held against the block statistics of the reference's published renders (see tests/readme_util.py)
-    from tests.readme_util import CONFIGS, compare
-    img, st = _gpu(G.scene_default(cube_obj)).render(make_config(1024, 1024, spp=200, **CONFIGS[key]))
-    corr, rel_rms, mean_dev = compare(key, img, 1024, 1024)
+    # The README's own configurations (1024x1024, 200 samples; BASELINE config C3 is the bidirectional one) through the
+    # HIP path, against the block statistics of the reference's published renders (tests/readme_util.py: classes of blocks).
+    # north_star's bar -- 1 % -- on everything the 255 clamp and the absent cube.obj do not blur:
+    #   channel means            measured 0.05 % / 0.04 %   (round 1: 2.6 % / 2.3 %)
+    #   64-pixel block rms       measured 0.84 % / 0.82 %   (round 1: 2.6 % / 3.7 %; ~0.7 % of it is the Monte-Carlo noise of
+    #                                                        two independent 200-sample pictures)
+    #   wall blocks, in sum      measured 0.15 % / 0.15 %;  blocks a cube touches 1.5 % / 1.1 % (palette, reconstructed cube.obj)
+    from tests.readme_util import CONFIGS, compare, cube_mask_of
+    desc = G.scene_default(cube_obj)
+    s = _gpu(desc)
+    cfg = make_config(1024, 1024, spp=200, **CONFIGS[key])
+    cfg.flags = FLAG_DROP_NONFINITE   # (a non-finite sample would saturate its pixel: one pixel in 10^6)
+    img, st = s.render(cfg)
+    r = compare(key, img, 1024, 1024, cube_mask_of(s, desc.camera, 1024))
+    print(key, r)
     assert st["samples"] == 1024 * 1024 * 200
-    assert corr > 0.995 and rel_rms < 0.05 and mean_dev < 0.04, (corr, rel_rms, mean_dev)  # measured 0.998/0.026/0.026, 0.996/0.037/0.023
+    assert r["corr"] > 0.995 and r["rel_rms"] < 0.012 and r["mean_dev"] < 0.005, r
+    assert r["walls"]["blocks"] > 800 and r["walls"]["sum_dev"] < 0.01 and r["walls"]["rel_rms"] < 0.025, r
+    assert r["cubes"]["sum_dev"] < 0.025 and r["saturated"]["sum_dev"] < 0.005, r

@@ -124,13 +124,19 @@ def test_obj_reader_swaps_y_z_and_bakes_srt(tmp_path):
 @pytest.mark.parametrize("key", ["simple_d6_200spp", "bidir_3_3_200spp"])
 def test_oracle_against_the_reference_readme_renders(key, cube_obj):
     """The only outputs of the reference itself that exist for this path: its two published 1024x1024, 200-sample renders
-    of the default scene (8-bit, tone-clamped, cuRAND, the author's cube.obj) -- a COARSE pin of the oracle's scene,
-    camera, light transport and image orientation, not a bit-level one: 16x16 block means of the oracle's 200-spp
-    render correlate > 0.99 with the reference's per channel, differ by < 8 % rms, channel means agree within 5 %
-    (measured: 0.994 / 4.7 % / 2.5 % simple, 0.994 / 5.1 % / 2.4 % bidirectional)."""
-    from tests.readme_util import CONFIGS, compare
-    o = G.scene_default(cube_obj).apply(B.OracleScene())
+    of the default scene (8-bit, tone-clamped, 256-colour palette, cuRAND, the author's cube.obj).  The oracle's own
+    200-sample render at 256x256 (a quarter of the resolution: the CPU suite's budget) against their block statistics:
+    channel means within 1 %, wall blocks (no cube, hardly a saturated pixel) within 1.5 % in sum.  Measured: means 0.23 % /
+    0.2 %, walls 0.23 % / 0.3 %, blocks a cube touches 1.4 % / 1.1 %.  (Round 1, before the point on a ray was evaluated with
+    a fused multiply-add like nvcc does: means 2.5 %, left wall 8-14 % too bright in red and blue.)
+    The full-resolution comparison runs on the GPU: tests/test_gpu_golden.py."""
+    from tests.readme_util import CONFIGS, compare, cube_mask_of
+    desc = G.scene_default(cube_obj)
+    o = desc.apply(B.OracleScene())
     o.commit()
-    img, _ = o.render(make_config(128, 128, spp=200, **CONFIGS[key]))
-    corr, rel_rms, mean_dev = compare(key, img, 128, 128)
-    assert corr > 0.99 and rel_rms < 0.08 and mean_dev < 0.05, (corr, rel_rms, mean_dev)
+    img, _ = o.render(make_config(256, 256, spp=200, **CONFIGS[key]))
+    img = np.nan_to_num(img, nan=0.0, posinf=0.0, neginf=0.0)
+    r = compare(key, img, 256, 256, cube_mask_of(o, desc.camera, 256))
+    print(key, r)
+    assert r["corr"] > 0.97 and r["mean_dev"] < 0.01, r
+    assert r["walls"]["blocks"] > 400 and r["walls"]["sum_dev"] < 0.015 and r["cubes"]["sum_dev"] < 0.03, r
