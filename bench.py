@@ -18,7 +18,8 @@ Extra objects on the JSON line:
                        time (HIP events) vs 8 TB/s;  `valu`  VALU busy fraction and lane use from the same passes;
                `algorithmic` what the production kernel reads by its own layout (counted by k_extend<kCountWork> in an
                        untimed step) -- memory-side / algorithmic < 1 is what the caches absorbed.
-               roofline.bound names the larger of the hbm and valu fractions; `reference_model` keeps SURVEY 8d's
+               roofline.bound names what binds (VALU issue busy vs memory side / the 6.3 TB/s a copy reaches); for a
+               VALU-bound kernel roofline.frac = busy x lane use (useful lane throughput / peak); `reference_model` keeps SURVEY 8d's
                reference-traversal byte model as a throughput normalisation (it is not a fraction of anything).
   cpu_baseline the CPU oracle ("port") rendering a bounded pixel-subsampled slice of the same workload.
   closest_hit  (N=1 only) Mrays/s of mipt_trace_closest_device on the 1,310,720-triangle icosphere (C4 mesh) for a
@@ -164,9 +165,13 @@ def roofline_views(pmc, launch_ms, rays_per_launch, alg_bpr, ref_bpr, extra=None
     r["algorithmic"]["memory_side_over_algorithmic"] = round(traffic / max(1.0, alg_bytes), 4)
     r["traffic"] = int(round(traffic))
     r["traffic_unit"] = "bytes per launch (TCC_MISS_sum x 128 + WRITE_SIZE)"
-    if busy >= hbm_gbs / HBM_PEAK_GBS:
-        r.update({"bound": "valu", "achieved": round(busy, 4), "peak": 1.0, "unit": "VALU busy fraction of kernel cycles",
-                  "frac": round(busy, 4)})
+    # which resource binds: the VALU issue slots (busy) or the memory side (against the ~6.3 TB/s a copy achieves).  The
+    # fraction reported for a VALU-bound kernel is USEFUL lane throughput / peak lane throughput = busy x lane use: an
+    # issue slot spent on a wave with most lanes masked off is not progress.
+    if busy >= hbm_gbs / HBM_MEASURED_COPY_GBS:
+        r.update({"bound": "valu", "achieved": round(busy * lane, 4), "peak": 1.0,
+                  "unit": "fraction of peak VALU lane throughput (issue-slot busy x lanes active)", "frac": round(busy * lane, 4),
+                  "issue_busy_frac": round(busy, 4)})
     else:
         r.update({"bound": "hbm", "achieved": round(hbm_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                   "frac": round(hbm_gbs / HBM_PEAK_GBS, 4)})
@@ -287,6 +292,7 @@ def main():
     ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 --pmc child passes (roofline.frac is then withheld)")
     ap.add_argument("--no-strong", action="store_true")
     ap.add_argument("--pmc-timeout", type=float, default=150.0)
+    ap.add_argument("--save-pmc", default=None, help="write the per-launch counter means of the PMC passes to this JSON file")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--backend", default="nccl", help="process-group backend (nccl = RCCL)")
     args = ap.parse_args()
@@ -311,6 +317,9 @@ def main():
     pmc, pmc_source = None, "skipped (--no-pmc or N > 1)"
     if world == 1 and not args.no_pmc:
         pmc, pmc_source = collect_pmc(args, log)
+        if pmc is not None and args.save_pmc:
+            json.dump({"parts": pmc, "passes": [list(p) for p in PMC_PASSES], "note": "mean per k_extend<kProd> launch; rocprofv3 --pmc, one pass per list"},
+                      open(args.save_pmc, "w"), indent=1)
         if pmc is None:
             log("PMC collection failed: " + pmc_source)
             fallback = os.path.join(ROOT, "profiles", "r2_pmc_bench.json")

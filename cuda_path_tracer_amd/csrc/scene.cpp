@@ -215,6 +215,7 @@ bool HostScene::pack(int n_threads, std::string &err) {
                 grow(l_empty ? INFINITY : l[2 * a], l_empty ? -INFINITY : l[2 * a + 1], rec[4 * a + 0], rec[4 * a + 2]);
                 grow(r_empty ? INFINITY : r[2 * a], r_empty ? -INFINITY : r[2 * a + 1], rec[4 * a + 1], rec[4 * a + 3]);
             }
+            memcpy(rec + 12, &nodes[lc], 2 * sizeof(KdNode));  // the children's nodes (global indices, flags set) ride along
         }
         });
         int32_t *refs = reinterpret_cast<int32_t *>(A + L.refs) + hm.ref_base;

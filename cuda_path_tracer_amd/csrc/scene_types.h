@@ -65,7 +65,7 @@ struct DScene {
     const KdNode *nodes;
     const f4 *boxes;
     const f4 *tight;        // per node, same layout as boxes: leaf cull box (triangle AABB within the leaf box)
-    const f4 *tight_pairs;  // per sibling pair (left child index >> 1), 64 B: the two cull boxes component-interleaved
+    const f4 *tight_pairs;  // per sibling pair (left child index >> 1), 64 B: the two cull boxes component-interleaved (48 B) + the two children's nodes (16 B)
                             // (loxL,loxR,hixL,hixR) (loyL,loyR,hiyL,hiyR) (lozL,lozR,hizL,hizR) (pad) for packed fp32
     const int32_t *refs;
     const f4 *leaf_planes;  // per leaf reference: (N.xyz, -dot(N,a)) of that triangle, in leaf order

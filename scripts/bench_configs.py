@@ -48,6 +48,9 @@ for name in which:
            "rays_per_sample": round(st["rays_total"] / st["samples"], 2), "ms_gpu": round(st["ms_total"], 1),
            "extend_share": round(st["ms_extend"] / st["ms_total"], 3), "wall_s_incl_readback": round(wall, 3),
            "commit_s": round(t_commit, 2), "kd_build_s": round(s.build_seconds(), 2), "arena_MB": round(s.device_bytes() / 1e6, 1),
-           "image_mean": float(img.mean()), "finite": bool(np.isfinite(img).all())}
+           "image_mean_finite_pixels": float(img[np.isfinite(img).all(axis=2)].mean()),
+           "nonfinite_pixels": int((~np.isfinite(img).all(axis=2)).sum()), "nonfinite_samples": int(st["nonfinite_samples"]),
+           "nonfinite_note": "the reference's own arithmetic (DESIGN.md 4.2: light_pdf == 0 at kernel.cu:277; sqrtf of a negative at "
+                             "samplers.cuh:19 through the env term); identical in the oracle, pinned by tests/test_gpu_full_configs.py"}
     print(json.dumps(out), flush=True)
     s.close()

@@ -1,7 +1,10 @@
 import json, sys
 l=[x for x in open(sys.argv[1]) if x.startswith('{')][-1]; d=json.loads(l)
 r=d['roofline']
-print("C2 samples/s %.3g  Mrays/s(kernel) %.1f  frac %.3f  ms/step %.1f" % (d['value'], r['Mrays_per_s_in_kernel'], r['frac'], d['ms_per_step']))
+def rf(r):
+    h=r.get('hbm'); v=r.get('valu')
+    return "bound %s frac %s | hbm %s B/ray %s L2hit %s | valu busy %s lane %s | alg B/ray %s" % (r.get('bound'), r.get('frac'), h and h['frac'], h and h['bytes_per_ray'], h and h['l2_hit_rate'], v and v['busy_frac'], v and v['lane_use'], r['algorithmic']['bytes_per_ray'])
+print("C2 samples/s %.4g  Mrays/s(kernel) %.1f  ms/step %.1f  k_extend ms/launch %.3f | %s" % (d['value'], r['Mrays_per_s_in_kernel'], d['ms_per_step'], r['avg_launch_ms'], rf(r)))
 for k in ('coherent','incoherent'):
     if 'closest_hit' in d:
-        c=d['closest_hit'][k]; print(k, c['Mrays_per_s'], c['roofline']['frac'], 'culled', c.get('culled_candidate_frac'), c.get('cpu_oracle'))
+        c=d['closest_hit'][k]; print("%-10s %7.1f Mrays/s | %s | %s" % (k, c['Mrays_per_s'], rf(c['roofline']), c.get('cpu_oracle')))
