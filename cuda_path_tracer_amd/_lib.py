@@ -64,6 +64,7 @@ SIGNATURES = {
     "mipt_trace_closest_device": (C.c_int, [_VP, C.c_int, _VP, _VP, C.c_int64, _VP, _VP, C.POINTER(Stats), C.c_int]),
     "mipt_trace_closest_device_noalloc": (C.c_int, [_VP, C.c_int, _VP, _VP, C.c_int64, _VP, _VP]),
     "mipt_env_lookup": (C.c_int, [_VP, _VP, C.c_int64, _VP]),
+    "mipt_scene_gpu_built_meshes": (C.c_int, [_VP]),
     "mipt_hdr_load_rgbe": (C.c_int, [C.c_char_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), _VP]),
     "mipt_mesh_count": (C.c_int, [_VP]),
     "mipt_kd_sizes": (C.c_int, [_VP, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
@@ -71,6 +72,7 @@ SIGNATURES = {
     "mipt_mesh_triangles": (C.c_int, [_VP, C.c_int, _VP, _VP]),
     "mipt_scene_device_bytes": (C.c_int64, [_VP]),
     "mipt_scene_build_seconds": (C.c_double, [_VP]),
+    "mipt_scene_kd_seconds": (C.c_double, [_VP]),
     "mipt_last_error": (C.c_char_p, []),
     "mipt_version": (C.c_char_p, []),
 }

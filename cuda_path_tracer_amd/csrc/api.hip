@@ -321,6 +321,10 @@ int mipt_scene_commit(mipt_scene *s, const int *device_ids, int n_devices) {
     s->committed = false;
     std::string err;
     // (a scene that is already packed -- committed before with no edit since, or imported -- is only uploaded)
+    {
+        const char *kb = getenv("MIPT_KD_BUILD");  // "host": every kd-tree on the host threads; default: large meshes on the first device
+        s->host.build_device = (n_devices > 0 && !(kb && strcmp(kb, "host") == 0)) ? device_ids[0] : -1;
+    }
     if (!s->host.packed && !s->host.pack(0, err)) return fail(-4, err);
     for (int i = 0; i < n_devices; i++) {
         DeviceCtx dc;
@@ -582,6 +586,8 @@ int mipt_hdr_load_rgbe(const char *path, int32_t *w, int32_t *h, uint32_t *texel
     return 0;
 }
 
+int mipt_scene_gpu_built_meshes(mipt_scene *s) { return s ? s->host.meshes_built_on_gpu : fail(-1, "null scene"); }
+
 int mipt_mesh_count(mipt_scene *s) { return s ? (int)s->host.meshes.size() : fail(-1, "null scene"); }
 
 int mipt_kd_sizes(mipt_scene *s, int mesh, int64_t *nn, int64_t *nr, int64_t *nt) {
@@ -665,5 +671,6 @@ int mipt_scene_import(mipt_scene *s, const void *blob, int64_t size) {
 
 int64_t mipt_scene_device_bytes(mipt_scene *s) { return s && s->host.packed ? (int64_t)s->host.arena.size() : 0; }
 double mipt_scene_build_seconds(mipt_scene *s) { return s ? s->host.build_seconds : 0.0; }
+double mipt_scene_kd_seconds(mipt_scene *s) { return s ? s->host.kd_seconds : 0.0; }
 
 }  // extern "C"

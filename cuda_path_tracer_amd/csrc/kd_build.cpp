@@ -177,7 +177,43 @@ void flatten(const TNode *nd, size_t idx, KdTree &out, int depth) {
     flatten(nd->right.get(), pair + 1, out, depth + 1);
 }
 
+void emit_flat(const std::vector<BuildNode> &tree, int i, size_t idx, const int32_t *leaf_refs, KdTree &out, int depth) {
+    const BuildNode &nd = tree[(size_t)i];
+    const float b[8] = {nd.lo[0], nd.hi[0], nd.lo[1], nd.hi[1], nd.lo[2], nd.hi[2], 0.f, 0.f};
+    std::copy(b, b + 8, out.boxes.begin() + 8 * idx);
+    out.max_depth = std::max(out.max_depth, depth);
+    if (nd.degenerate) out.degenerate_nodes++;
+    if (nd.left < 0) {
+        KdNode k;
+        k.a = (uint32_t)out.refs.size();
+        k.b = kLeafTag | (uint32_t)nd.leaf_count;
+        out.refs.insert(out.refs.end(), leaf_refs + nd.leaf_begin, leaf_refs + nd.leaf_begin + nd.leaf_count);
+        out.nodes[idx] = k;
+        out.n_leaves++;
+        out.max_leaf = std::max<int64_t>(out.max_leaf, (int64_t)nd.leaf_count);
+        return;
+    }
+    const size_t pair = out.nodes.size();
+    out.nodes.resize(pair + 2, KdNode{0, kLeafTag});
+    out.boxes.resize(8 * (pair + 2), 0.f);
+    KdNode k;
+    union { float f; uint32_t u; } cv;
+    cv.f = nd.split;
+    k.a = cv.u;
+    k.b = ((uint32_t)nd.axis << 30) | (uint32_t)pair;
+    out.nodes[idx] = k;
+    emit_flat(tree, nd.left, pair, leaf_refs, out, depth + 1);
+    emit_flat(tree, nd.right, pair + 1, leaf_refs, out, depth + 1);
+}
+
 }  // namespace
+
+void assemble_kd_tree(const std::vector<BuildNode> &tree, const int32_t *leaf_refs, KdTree &out) {
+    out = KdTree();
+    out.nodes.assign(2, KdNode{0, kLeafTag});  // root + one padding slot (an empty leaf nobody references)
+    out.boxes.assign(16, 0.f);
+    emit_flat(tree, 0, 0, leaf_refs, out, 0);
+}
 
 void build_kd_tree(const float *pos, int64_t n_tris, KdTree &out, int n_threads) {
     out = KdTree();

@@ -70,12 +70,23 @@ bool HostScene::pack(int n_threads, std::string &err) {
     for (const HostMesh &hm : meshes)
         if (hm.n_tris <= 0) { err = "empty mesh"; return false; }
     {
-        const int side_by_side = (int)std::max<size_t>(1, std::min<size_t>(meshes.size(), (size_t)n_threads));
+        constexpr int64_t kGpuBuildMinTris = 16384;  // below that the host build takes a few milliseconds
+        std::vector<size_t> on_host;
+        meshes_built_on_gpu = 0;
+        for (size_t m = 0; m < meshes.size(); m++) {
+            if (build_device >= 0 && meshes[m].n_tris >= kGpuBuildMinTris) {
+                if (!build_kd_tree_gpu(build_device, meshes[m].pos.data(), meshes[m].n_tris, trees[m], err)) return false;
+                meshes_built_on_gpu++;
+            } else {
+                on_host.push_back(m);
+            }
+        }
+        const int side_by_side = (int)std::max<size_t>(1, std::min<size_t>(on_host.size(), (size_t)n_threads));
         const int threads_each = std::max(1, n_threads / side_by_side);
         std::atomic<size_t> next{0};
         auto worker = [&]() {
-            for (size_t m = next.fetch_add(1); m < meshes.size(); m = next.fetch_add(1))
-                build_kd_tree(meshes[m].pos.data(), meshes[m].n_tris, trees[m], threads_each);
+            for (size_t k = next.fetch_add(1); k < on_host.size(); k = next.fetch_add(1))
+                build_kd_tree(meshes[on_host[k]].pos.data(), meshes[on_host[k]].n_tris, trees[on_host[k]], threads_each);
         };
         std::vector<std::thread> pool;
         for (int w = 1; w < side_by_side; w++) pool.emplace_back(worker);
@@ -102,6 +113,7 @@ bool HostScene::pack(int n_threads, std::string &err) {
         return false;
     }
     const double t_trees = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    kd_seconds = t_trees;
     ArenaLayout L;
     size_t off = 0;
     auto section = [&](size_t bytes) { size_t o = off; off = align_up(off + std::max<size_t>(bytes, 16), 256); return o; };
@@ -394,7 +406,7 @@ bool HostScene::pack(int n_threads, std::string &err) {
     layout = L;
     packed = true;
     build_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-    if (getenv("MIPT_TIMING")) fprintf(stderr, "[mipt] kd trees %.3f s, pack %.3f s (%d threads)\n", t_trees, build_seconds - t_trees, n_threads);
+    if (getenv("MIPT_TIMING")) fprintf(stderr, "[mipt] kd trees %.3f s (%d of %d meshes on the GPU), pack %.3f s (%d threads)\n", t_trees, meshes_built_on_gpu, (int)meshes.size(), build_seconds - t_trees, n_threads);
     return true;
 }
 

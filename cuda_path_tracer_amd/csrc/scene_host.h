@@ -44,12 +44,17 @@ struct HostScene {
     std::vector<HostMesh> meshes;
     HostEnv env;
 
+    // kd-trees of meshes with at least kGpuBuildMinTris triangles are built on this HIP device (kd_build_gpu.hip); -1: all on
+    // the host.  Set by mipt_scene_commit when it has a device and MIPT_KD_BUILD is not "host".  Both builders make the same tree.
+    int build_device = -1;
+    int meshes_built_on_gpu = 0;
     bool packed = false;
     bool imported = false;       // packed state came from mipt_scene_import: no triangle arrays on the host, nothing to rebuild
     std::vector<uint8_t> arena;  // host copy of the device arena
     ArenaLayout layout;
     int64_t total_tris = 0, total_nodes = 0, total_refs = 0;
-    double build_seconds = 0.0;
+    double build_seconds = 0.0;  // kd-trees + pack
+    double kd_seconds = 0.0;     // kd-trees alone
 
     // Build kd-trees and pack everything into `arena`.  Returns false and sets err on failure.
     bool pack(int n_threads, std::string &err);

@@ -201,8 +201,15 @@ class Scene:
         check(self._lib.mipt_mesh_triangles(self._h, int(mesh), _ptr(pos), _ptr(nrm)))
         return pos, nrm
 
+    def gpu_built_meshes(self):
+        """Meshes whose kd-tree the last commit built on the GPU (the others: host threads; same tree either way)."""
+        return check(self._lib.mipt_scene_gpu_built_meshes(self._h))
+
     def device_bytes(self):
         return int(self._lib.mipt_scene_device_bytes(self._h))
 
     def build_seconds(self):
         return float(self._lib.mipt_scene_build_seconds(self._h))
+
+    def kd_seconds(self):
+        return float(self._lib.mipt_scene_kd_seconds(self._h))

@@ -136,6 +136,10 @@ int  mipt_env_lookup(mipt_scene *, const float *dirs, int64_t n, float *rgb);
 int  mipt_hdr_load_rgbe(const char *path, int32_t *w, int32_t *h, uint32_t *texels /* w*h or NULL */);
 
 /* ---- introspection of the packed scene (host side; valid after commit) ---------------- */
+/* How many meshes' kd-trees the last commit built on the GPU (Node::makeNodeTree mesh.cu:32-136 level by level, kd_build_gpu.hip)
+ * rather than on the host threads: meshes of >= 16,384 triangles when the commit has a device, unless MIPT_KD_BUILD=host.
+ * Both builders produce the same tree, bit for bit. */
+int  mipt_scene_gpu_built_meshes(mipt_scene *);
 int  mipt_mesh_count(mipt_scene *);
 int  mipt_kd_sizes(mipt_scene *, int mesh, int64_t *n_nodes, int64_t *n_refs, int64_t *n_tris);
 /* Unpacks the 8-byte nodes of one mesh: boxes n*6 (minX,maxX,minY,maxY,minZ,maxZ), axis, left/right child
@@ -144,7 +148,8 @@ int  mipt_kd_export(mipt_scene *, int mesh, float *boxes, int32_t *axis, int32_t
                     int32_t *first, int32_t *count, int32_t *refs);
 int  mipt_mesh_triangles(mipt_scene *, int mesh, float *pos9, float *nrm9);
 int64_t mipt_scene_device_bytes(mipt_scene *);   /* size of the packed arena */
-double  mipt_scene_build_seconds(mipt_scene *);  /* host kd build + pack time of the last commit */
+double  mipt_scene_build_seconds(mipt_scene *);  /* kd build + pack time of the last commit */
+double  mipt_scene_kd_seconds(mipt_scene *);     /* ... of which the kd-trees (host threads and / or GPU) */
 
 const char *mipt_last_error(void);   /* replaces fprintf(stderr, ...) and continue (copyToDevice.h:10-17) */
 const char *mipt_version(void);
