@@ -60,6 +60,104 @@ __device__ __forceinline__ void flush_counters(const TravCounters &tc, unsigned 
     }
 }
 
+// ---- leaf scan with a wave-cooperative second pass ------------------------------------------------------------------
+// leaf_scan() (traverse.h) lets every lane evaluate its own marked candidates one after another: the wave runs that ~100-
+// instruction body as often as its busiest lane has marks, with a third (C2) to an eighth (incoherent batches) of the
+// lanes in it.  Here the marks of all lanes waiting at a leaf are pooled instead: each owner writes (owner lane, reference)
+// items into a per-wave LDS list at its prefix-sum offset, the 64 lanes take the items 64 at a time -- the owner's ray and
+// leaf box come over by ds_bpermute -- and a passed candidate goes back as an LDS atomicMin on the key (bits(t) << 32 |
+// reference): the smallest t, and among equal t the earliest reference, which is what the reference's sequential
+// "t < best" rule keeps (mesh.cuh:293-297; t > 0, so its bits order like the value).  Must be called by all 64 lanes.
+constexpr int kCoopItems = 128;  // items per round and wave (more marks wait for the next round)
+
+__device__ __forceinline__ float plane_candidate_nobest(f4 pl, f3 o, f3 d, const float lo[3], const float hi[3]) {
+    const f3 N = mk3(pl.x, pl.y, pl.z);
+    const float nd = dot3(N, d);
+    if (fabsf(nd) < kEps) return -1.0f;  // Q3
+    const float t = -(dot3(N, o) + pl.w) / nd;
+    if (!(t > 0.0f)) return -1.0f;
+    const f3 P = ray_at(o, d, t);
+    if (!point_in_box(P, lo[0], hi[0], lo[1], hi[1], lo[2], hi[2])) return -1.0f;
+    return t;
+}
+
+template <bool WORK>
+__device__ __forceinline__ void leaf_scan_coop(const DScene &sc, bool pending, int first, int count, f3 o, f3 d, const SlabBox &cur,
+                                               float &bt, int &bi, WorkCounters &wc, int *items, unsigned long long *res PSTAT_ARG) {
+    const int lane = (int)(threadIdx.x & 63u);
+    const int end = first + count;
+    unsigned long long best_key = ~0ull;
+    if (WORK && pending) wc.leaves++;
+    for (int base = first & ~1;; base += 64) {
+        const bool active = pending && base < end;
+        if (__ballot(active) == 0ull) break;
+        unsigned long long marked = 0ull;
+        if (active) {  // pass 1: the candidate spheres, exactly as in leaf_scan()
+            const int stop = (end - base < 64) ? end - base : 64;
+            const SpherePair *sp = sc.leaf_spheres + (base >> 1);
+            for (int p = 0; 2 * p < stop; p += 2) {
+                PSTAT(ps, 5);
+                const SpherePair s0 = sp[p], s1 = sp[p + 1];
+                if (WORK) wc.sphere_pairs += 2;
+                marked |= (unsigned long long)(sphere_pair_hit(s0, o, d) | (sphere_pair_hit(s1, o, d) << 2)) << (2 * p);
+            }
+            marked &= (stop < 64 ? (1ull << stop) - 1ull : ~0ull) & ~((1ull << (first > base ? first - base : 0)) - 1ull);
+        }
+        while (__ballot(marked != 0ull) != 0ull) {  // pass 2, pooled over the wave
+            const int c = __popcll(marked);
+            int incl = c;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const int v = __shfl_up(incl, off, 64);
+                if (lane >= off) incl += v;
+            }
+            const int total = __shfl(incl, 63, 64);
+            res[lane] = ~0ull;
+            for (int pos = incl - c; marked != 0ull && pos < kCoopItems; pos++) {
+                const int bit = __builtin_ffsll((long long)marked) - 1;
+                marked &= marked - 1ull;
+                items[pos] = lane;
+                items[kCoopItems + pos] = base + bit;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const int T = total < kCoopItems ? total : kCoopItems;
+            for (int i0 = 0; i0 < T; i0 += 64) {  // wave-uniform trip count: every lane takes part in the shuffles
+                const int i = i0 + lane;
+                const bool valid = i < T;
+                const int p = valid ? items[i] : lane;
+                const int r = valid ? items[kCoopItems + i] : 0;
+                const f3 fo = mk3(__shfl(o.x, p, 64), __shfl(o.y, p, 64), __shfl(o.z, p, 64));
+                const f3 fd = mk3(__shfl(d.x, p, 64), __shfl(d.y, p, 64), __shfl(d.z, p, 64));
+                const float flo[3] = {__shfl(cur.lo[0], p, 64), __shfl(cur.lo[1], p, 64), __shfl(cur.lo[2], p, 64)};
+                const float fhi[3] = {__shfl(cur.hi[0], p, 64), __shfl(cur.hi[1], p, 64), __shfl(cur.hi[2], p, 64)};
+                if (valid) {
+                    PSTAT(ps, 6);
+                    const f4 pl = sc.leaf_planes[r];
+                    const float t = plane_candidate_nobest(pl, fo, fd, flo, fhi);
+                    if (WORK) wc.planes++;
+                    if (t > 0.0f) {
+                        if (WORK) wc.verts++;
+                        const f4 pa = sc.leaf_verts[3 * (size_t)r], pb = sc.leaf_verts[3 * (size_t)r + 1], pc = sc.leaf_verts[3 * (size_t)r + 2];
+                        if (inside_triangle(pl, mk3(pa.x, pa.y, pa.z), mk3(pb.x, pb.y, pb.z), mk3(pc.x, pc.y, pc.z), fo, fd, t))
+                            atomicMin(&res[p], ((unsigned long long)as_u32(t) << 32) | (unsigned long long)(unsigned int)r);
+                    }
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const unsigned long long k = res[lane];
+            if (pending && k < best_key) best_key = k;
+        }
+    }
+    bt = -1.0f;
+    bi = -1;
+    if (pending && best_key != ~0ull) {
+        bt = as_f32((uint32_t)(best_key >> 32));
+        bi = sc.refs[(int)(uint32_t)best_key];  // reference position -> triangle id, once per leaf
+    }
+}
+
 // rays: o/d as float4 (w not read here), d already normalised by the Ray constructor rule (ray.cuh:10).
 // hits: on entry the sphere / plane answer of every ray (quadrics_closest, written by the stage that made the ray),
 //       on exit the closest hit of the scene.
@@ -75,7 +173,11 @@ __global__ __launch_bounds__(kExtendBlock, 5) void k_extend(DScene sc, const f4 
     constexpr bool COUNT = MODE == kCountRef;
     constexpr bool WORK = MODE == kCountWork;
     __shared__ int stack_mem[kStackDepth * kExtendBlock];
+    __shared__ int coop_items[(kExtendBlock / 64) * 2 * kCoopItems];
+    __shared__ unsigned long long coop_res[kExtendBlock];
     LdsStack stk{stack_mem + threadIdx.x};
+    int *const my_items = coop_items + (threadIdx.x >> 6) * 2 * kCoopItems;
+    unsigned long long *const my_res = coop_res + (threadIdx.x & ~63u);
     const int n = count_ptr ? *count_ptr : n_fixed;
     const int lane = (int)(threadIdx.x & 63u);
     // the 8 ranges of the queue (multiples of 64 rays) and the one this wave pulls from
@@ -252,12 +354,12 @@ __global__ __launch_bounds__(kExtendBlock, 5) void k_extend(DScene sc, const f4 
         {
             const int n_pend = __popcll(__ballot(pending));
             const int n_trav = __popcll(__ballot(has_ray && !pending && !start_mesh));
-            if (n_pend >= tune.leaf_batch_lanes || (n_pend > 0 && n_trav < tune.leaf_batch_lanes)) {
+            if (n_pend >= tune.leaf_batch_lanes || (n_pend > 0 && n_trav < tune.leaf_batch_lanes)) {  // wave-uniform
+                float bt;
+                int bi;
+                if (pending) { PSTAT(ps, 4); }
+                leaf_scan_coop<WORK>(sc, pending, (int)nd.a, (int)(nd.b & kIdxMask), o, d, cur, bt, bi, wc, my_items, my_res PSTAT_PASS);
                 if (pending) {
-                    float bt;
-                    int bi;
-                    PSTAT(ps, 4);
-                    leaf_scan<WORK>(sc, (int)nd.a, (int)(nd.b & kIdxMask), o, d, cur, bt, bi, wc PSTAT_PASS);
                     pending = false;
                     after_leaf(bt, bi);
                 }
