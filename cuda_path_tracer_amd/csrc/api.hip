@@ -118,6 +118,7 @@ void clamp_tuning(ExtendTuning &t) {
     t.refill_lanes = std::min(64, std::max(1, t.refill_lanes));
     t.leaf_batch_lanes = std::min(64, std::max(1, t.leaf_batch_lanes));
     t.step_cap = std::min(64, std::max(1, t.step_cap));
+    t.pool1_below = std::min(65, std::max(0, t.pool1_below));
 }
 
 int setup_device(mipt_scene *s, DeviceCtx &dc) {
@@ -138,9 +139,10 @@ int setup_device(mipt_scene *s, DeviceCtx &dc) {
     dc.extend_simple = ev && std::string(ev) == "simple";
     if (const char *sv = getenv("MIPT_SHADOW_SORT")) dc.shadow_sort_from = atoi(sv);
     if (const char *hv = getenv("MIPT_HEADS")) dc.n_heads = atoi(hv) == 1 ? 1 : 8;
-    if (const char *tv = getenv("MIPT_TUNE")) sscanf(tv, "%d,%d,%d", &dc.tune.refill_lanes, &dc.tune.leaf_batch_lanes, &dc.tune.step_cap);
+    if (const char *tv = getenv("MIPT_TUNE")) sscanf(tv, "%d,%d,%d,%d", &dc.tune.refill_lanes, &dc.tune.leaf_batch_lanes, &dc.tune.step_cap, &dc.tune.pool1_below);
     if (const char *tv = getenv("MIPT_TUNE_COHERENT"))
-        sscanf(tv, "%d,%d,%d", &dc.tune_coherent.refill_lanes, &dc.tune_coherent.leaf_batch_lanes, &dc.tune_coherent.step_cap);
+        sscanf(tv, "%d,%d,%d,%d", &dc.tune_coherent.refill_lanes, &dc.tune_coherent.leaf_batch_lanes, &dc.tune_coherent.step_cap,
+               &dc.tune_coherent.pool1_below);
     clamp_tuning(dc.tune);
     clamp_tuning(dc.tune_coherent);
     dc.view = s->host.view(dc.arena);

@@ -58,6 +58,7 @@ struct ExtendTuning {
     int refill_lanes = 32;      // refill a wave once this many lanes are idle (or all of them)
     int leaf_batch_lanes = 28;  // scan leaves once this many lanes wait at one (or fewer lanes than this still traverse)
     int step_cap = 4;           // node steps per lane per round before lanes re-converge
+    int pool1_below = 40;       // fewer lanes than this waiting at a leaf: the sphere pass is pooled over the wave too (kernels_extend.h)
     int common_origin = 0;      // per launch: 0 = rays carry their origins, 1 = all start at the eye, 2 = all start at lights[0]
     int n_heads = 8;            // ray cursors of the launch (8: one per XCD; 1: a single word, for A/B timing -- MIPT_HEADS)
     // (defaults from the sweeps of scripts/tune.sh on MI355X; the optimum is flat within ~3 % around them)

@@ -81,36 +81,86 @@ __device__ __forceinline__ float plane_candidate_nobest(f4 pl, f3 o, f3 d, const
     return t;
 }
 
+// wave-wide inclusive prefix sum of a small per-lane count
+__device__ __forceinline__ int wave_incl_scan(int v, int lane) {
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int u = __shfl_up(v, off, 64);
+        if (lane >= off) v += u;
+    }
+    return v;
+}
+
 template <bool WORK>
 __device__ __forceinline__ void leaf_scan_coop(const DScene &sc, bool pending, int first, int count, f3 o, f3 d, const SlabBox &cur,
-                                               float &bt, int &bi, WorkCounters &wc, int *items, unsigned long long *res PSTAT_ARG) {
+                                               float &bt, int &bi, WorkCounters &wc, int *block_items, unsigned long long *block_res,
+                                               bool pool_pass1 PSTAT_ARG) {
     const int lane = (int)(threadIdx.x & 63u);
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // scalar: the per-wave LDS bases cost no VGPR
+    int *const items = block_items + wave * 2 * kCoopItems;
+    unsigned long long *const res = block_res + wave * 64;
     const int end = first + count;
     unsigned long long best_key = ~0ull;
     if (WORK && pending) wc.leaves++;
     for (int base = first & ~1;; base += 64) {
         const bool active = pending && base < end;
         if (__ballot(active) == 0ull) break;
+        // ---- pass 1: the candidate spheres.  With most lanes of the wave waiting at a leaf every lane streams its own leaf
+        // (as leaf_scan() does); with few of them (pool_pass1, wave-uniform) the work is pooled: a unit = 4 candidates = two
+        // sphere pairs (64 B), the owners list their units, the 64 lanes take them 64 at a time (owner's ray by ds_bpermute)
+        // and OR the marks into the owner's 64-bit mask in LDS.
+        const int stop = active ? ((end - base < 64) ? end - base : 64) : 0;
         unsigned long long marked = 0ull;
-        if (active) {  // pass 1: the candidate spheres, exactly as in leaf_scan()
-            const int stop = (end - base < 64) ? end - base : 64;
-            const SpherePair *sp = sc.leaf_spheres + (base >> 1);
-            for (int p = 0; 2 * p < stop; p += 2) {
-                PSTAT(ps, 5);
-                const SpherePair s0 = sp[p], s1 = sp[p + 1];
-                if (WORK) wc.sphere_pairs += 2;
-                marked |= (unsigned long long)(sphere_pair_hit(s0, o, d) | (sphere_pair_hit(s1, o, d) << 2)) << (2 * p);
+        if (!pool_pass1) {
+            if (active) {
+                const SpherePair *sp = sc.leaf_spheres + (base >> 1);
+                for (int p = 0; 2 * p < stop; p += 2) {
+                    PSTAT(ps, 5);
+                    const SpherePair s0 = sp[p], s1 = sp[p + 1];
+                    if (WORK) wc.sphere_pairs += 2;
+                    marked |= (unsigned long long)(sphere_pair_hit(s0, o, d) | (sphere_pair_hit(s1, o, d) << 2)) << (2 * p);
+                }
             }
-            marked &= (stop < 64 ? (1ull << stop) - 1ull : ~0ull) & ~((1ull << (first > base ? first - base : 0)) - 1ull);
+        } else {
+            const int n_units = (stop + 3) >> 2;
+            int next_unit = 0;
+            res[lane] = 0ull;
+            while (__ballot(next_unit < n_units) != 0ull) {
+                const int c = n_units - next_unit;
+                const int incl = wave_incl_scan(c, lane);
+                const int total = __shfl(incl, 63, 64);
+                for (int pos = incl - c; next_unit < n_units && pos < 2 * kCoopItems; pos++, next_unit++) items[pos] = lane | (next_unit << 8);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                const int T = total < 2 * kCoopItems ? total : 2 * kCoopItems;
+                for (int i0 = 0; i0 < T; i0 += 64) {
+                    const int i = i0 + lane;
+                    const bool valid = i < T;
+                    const int it = valid ? items[i] : lane;
+                    const int p = it & 63, u = it >> 8;
+                    const f3 fo = mk3(__shfl(o.x, p, 64), __shfl(o.y, p, 64), __shfl(o.z, p, 64));
+                    const f3 fd = mk3(__shfl(d.x, p, 64), __shfl(d.y, p, 64), __shfl(d.z, p, 64));
+                    const int ffirst = __shfl(first, p, 64);
+                    if (valid) {
+                        PSTAT(ps, 5);
+                        const SpherePair *sp = sc.leaf_spheres + (((ffirst & ~1) + (base - (first & ~1))) >> 1) + 2 * u;
+                        const SpherePair s0 = sp[0], s1 = sp[1];
+                        if (WORK) wc.sphere_pairs += 2;
+                        const unsigned long long m4 = (unsigned long long)(sphere_pair_hit(s0, fo, fd) | (sphere_pair_hit(s1, fo, fd) << 2));
+                        if (m4 != 0ull) atomicOr(&res[p], m4 << (4 * u));
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            }
+            marked = res[lane];
+            __builtin_amdgcn_wave_barrier();
         }
-        while (__ballot(marked != 0ull) != 0ull) {  // pass 2, pooled over the wave
+        marked &= (stop < 64 ? (1ull << stop) - 1ull : ~0ull) & ~((1ull << (first > base ? first - base : 0)) - 1ull);
+        // ---- pass 2, pooled: items = (owner, reference)
+        while (__ballot(marked != 0ull) != 0ull) {
             const int c = __popcll(marked);
-            int incl = c;
-#pragma unroll
-            for (int off = 1; off < 64; off <<= 1) {
-                const int v = __shfl_up(incl, off, 64);
-                if (lane >= off) incl += v;
-            }
+            const int incl = wave_incl_scan(c, lane);
             const int total = __shfl(incl, 63, 64);
             res[lane] = ~0ull;
             for (int pos = incl - c; marked != 0ull && pos < kCoopItems; pos++) {
@@ -176,8 +226,6 @@ __global__ __launch_bounds__(kExtendBlock, 5) void k_extend(DScene sc, const f4 
     __shared__ int coop_items[(kExtendBlock / 64) * 2 * kCoopItems];
     __shared__ unsigned long long coop_res[kExtendBlock];
     LdsStack stk{stack_mem + threadIdx.x};
-    int *const my_items = coop_items + (threadIdx.x >> 6) * 2 * kCoopItems;
-    unsigned long long *const my_res = coop_res + (threadIdx.x & ~63u);
     const int n = count_ptr ? *count_ptr : n_fixed;
     const int lane = (int)(threadIdx.x & 63u);
     // the 8 ranges of the queue (multiples of 64 rays) and the one this wave pulls from
@@ -358,7 +406,7 @@ __global__ __launch_bounds__(kExtendBlock, 5) void k_extend(DScene sc, const f4 
                 float bt;
                 int bi;
                 if (pending) { PSTAT(ps, 4); }
-                leaf_scan_coop<WORK>(sc, pending, (int)nd.a, (int)(nd.b & kIdxMask), o, d, cur, bt, bi, wc, my_items, my_res PSTAT_PASS);
+                leaf_scan_coop<WORK>(sc, pending, (int)nd.a, (int)(nd.b & kIdxMask), o, d, cur, bt, bi, wc, coop_items, coop_res, n_pend < tune.pool1_below PSTAT_PASS);
                 if (pending) {
                     pending = false;
                     after_leaf(bt, bi);

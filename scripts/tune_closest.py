@@ -20,7 +20,17 @@ for kind in ("coherent", "incoherent"):
 print(" ".join(out))
 ''' % ROOT
 tunes = sys.argv[1:] or ["32,28,4", "32,28,6", "32,28,8", "32,28,12", "24,28,6", "40,28,6", "48,28,6", "32,20,6", "32,36,6", "32,44,6", "16,28,6", "24,20,8", "40,36,8"]
+import json
 for t in tunes:
-    env = dict(os.environ, MIPT_TUNE=t)
+    tc = os.environ.get("COHERENT_REFILL", "60") + "," + ",".join(t.split(",")[1:])  # coherent queues: same batch / cap, own refill
+    env = dict(os.environ, MIPT_TUNE=t, MIPT_TUNE_COHERENT=tc)
     r = subprocess.run([sys.executable, "-c", WORKER], env=env, capture_output=True, text=True, timeout=200)
-    print("TUNE=%-10s %s" % (t, r.stdout.strip().splitlines()[-1] if r.returncode == 0 and r.stdout.strip() else "FAILED " + r.stderr[-200:]), flush=True)
+    line = r.stdout.strip().splitlines()[-1] if r.returncode == 0 and r.stdout.strip() else "FAILED " + r.stderr[-200:]
+    b = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--no-pmc", "--no-cpu-baseline", "--no-closest"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    try:
+        d = json.loads([l for l in b.stdout.splitlines() if l.startswith("{")][-1])
+        c2 = "C2 %.1f Msamples/s (kernel %.1f Mrays/s)" % (d["value"] / 1e6, d["roofline"]["Mrays_per_s_in_kernel"])
+    except Exception:
+        c2 = "C2 FAILED " + b.stderr[-200:]
+    print("TUNE=%-10s COHERENT=%-10s %s  %s" % (t, tc, line, c2), flush=True)
