@@ -168,7 +168,8 @@ def roofline_views(pmc, launch_ms, rays_per_launch, alg_bpr, ref_bpr, extra=None
     # which resource binds: the VALU issue slots (busy) or the memory side (against the ~6.3 TB/s a copy achieves).  The
     # fraction reported for a VALU-bound kernel is USEFUL lane throughput / peak lane throughput = busy x lane use: an
     # issue slot spent on a wave with most lanes masked off is not progress.
-    if busy >= hbm_gbs / HBM_MEASURED_COPY_GBS:
+    # (memory-side bytes above the HBM peak can only have come from the Infinity Cache: then HBM is not what binds)
+    if busy >= hbm_gbs / HBM_MEASURED_COPY_GBS or hbm_gbs > HBM_PEAK_GBS:
         r.update({"bound": "valu", "achieved": round(busy * lane, 4), "peak": 1.0,
                   "unit": "fraction of peak VALU lane throughput (issue-slot busy x lanes active)", "frac": round(busy * lane, 4),
                   "issue_busy_frac": round(busy, 4)})
