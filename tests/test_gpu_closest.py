@@ -161,3 +161,13 @@ def test_empty_batch():
     s, _ = _pair(G.scene_icosphere_room(2))
     p, t, _ = s.trace_closest(np.zeros((0, 3), np.float32), np.zeros((0, 3), np.float32))
     assert p.shape == (0,) and t.shape == (0,)
+
+
+@pytest.mark.parametrize("tune", ["32,28,4,0", "32,28,4,65", "8,4,2,65", "60,60,8,0"])
+def test_leaf_scan_pooling_modes_change_no_result(tune, monkeypatch):
+    """The wave-cooperative leaf scan (kernels_extend.h: leaf_scan_coop) with the candidate-sphere pass never pooled (4th value
+    0), always pooled (65) and under extreme scheduling knobs: same primitive and t as the oracle, bit for bit."""
+    monkeypatch.setenv("MIPT_TUNE", tune)
+    monkeypatch.setenv("MIPT_TUNE_COHERENT", tune)
+    _check(G.scene_icosphere_room(5), 32768, lattice=10)
+    _check(G.scene_multi_sphere(3), 16384)
