@@ -244,11 +244,13 @@ def closest_hit_bench(torch, G, Scene, n_rays, with_cpu, pmc):
 
 
 # ----------------------------------------------------------------------------------------------- launching ranks
-def launch_ranks(n, argv):
+def launch_ranks(n, argv, share_gpu=False):
     """`python bench.py --gpus N` outside torchrun: start N rank processes (fresh interpreters; this parent never touches
     a GPU) and exit with the worst of their codes.  Rank 0 prints the JSON line on our stdout."""
     import torch  # device_count() does not initialise the GPU
     have = torch.cuda.device_count()
+    if share_gpu and have >= 1:
+        have = n  # rehearsal: every rank uses device 0 (gloo only; RCCL refuses two ranks on one GPU)
     if have < n:
         sys.stderr.write("bench.py: --gpus %d asked for, %d visible device(s): refusing to run a smaller job under that label\n" % (n, have))
         return 3
@@ -295,13 +297,18 @@ def main():
     ap.add_argument("--pmc-timeout", type=float, default=150.0)
     ap.add_argument("--save-pmc", default=None, help="write the per-launch counter means of the PMC passes to this JSON file")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
-    ap.add_argument("--backend", default="nccl", help="process-group backend (nccl = RCCL)")
+    ap.add_argument("--backend", default="nccl", help="process-group backend (nccl = RCCL; gloo: collectives staged through the host)")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="rehearsal of the N > 1 path on a one-GPU box: every rank renders on device 0 (needs --backend gloo; "
+                         "the line is labelled, its value is not a scaling number)")
     args = ap.parse_args()
 
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
-        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
+        if args.share_gpu and args.backend == "nccl":
+            raise SystemExit("bench.py: --share-gpu needs --backend gloo (RCCL refuses two ranks on one GPU)")
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:], args.share_gpu))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -333,6 +340,8 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+    if args.share_gpu:
+        local_rank = 0
     if torch.cuda.device_count() <= local_rank:
         raise SystemExit("bench.py: rank %d has no device %d" % (rank, local_rank))
     torch.cuda.set_device(local_rank)
@@ -368,7 +377,13 @@ def main():
             return scene.render_device(cfg, accum.data_ptr())
         return render_into
 
-    all_reduce = dist.all_reduce if world > 1 else None
+    def host_staged_all_reduce(t, op=None):  # gloo: reduce a host copy, write it back (rehearsals; RCCL reduces in place)
+        h = t.cpu()
+        dist.all_reduce(h) if op is None else dist.all_reduce(h, op=op)
+        t.copy_(h)
+
+    reduce_fn = dist.all_reduce if args.backend == "nccl" else host_staged_all_reduce
+    all_reduce = reduce_fn if world > 1 else None
     scratch = torch.zeros(W * H * 3, dtype=torch.float32, device="cuda")
     accum = torch.zeros(W * H * 3, dtype=torch.float32, device="cuda")
     spp_total = K * S * world  # normalisation constant of the timed render (kernel.cu:343)
@@ -395,7 +410,7 @@ def main():
         dt = time.perf_counter() - t0
         if world > 1:
             tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            reduce_fn(tt, op=dist.ReduceOp.MAX)
             dt = float(tt.item())
         return dt, stats
 
@@ -425,6 +440,7 @@ def main():
             "metric": "samples_per_sec", "value": round(samples_all / elapsed, 1), "unit": "pixel-samples/s",
             "n_gpus": world, "steps": K, "warmup": Wm, "ms_per_step": round(elapsed / K * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            **({"rehearsal": "all %d ranks shared ONE GPU over gloo: checks the N > 1 code path, not scaling" % world} if args.share_gpu else {}),
             "config": {"workload": "C2: box room + icosphere L%d (%d tris), simple PT depth 6, %dx%d, %d spp per GPU"
                                    % (args.level, 20 * 4 ** args.level, W, H, K * S),
                        "spp_per_step": S, "integrator": "simple", "cam_depth": 6, "parallelism": "spp-interleave x%d + all-reduce" % world,
