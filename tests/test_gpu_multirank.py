@@ -36,3 +36,20 @@ def test_two_ranks_on_one_gpu_render_the_single_rank_frame():
     assert one["n_gpus"] == 1 and "rehearsal" not in one and "strong" not in one
     assert np.isclose(two["image_mean"], one["image_mean"], rtol=2e-6), (two["image_mean"], one["image_mean"])
     assert two["rays_per_sample"] > 0
+
+
+def test_in_process_rccl_reduce_on_a_one_device_communicator(monkeypatch):
+    """mipt_render's device-side combine (api.hip: dlopen(librccl) -> ncclCommInitAll -> ncclReduce to slot 0, the replacement
+    of the D2H copy of kernel.cu:416 at G > 1) forced on for the single device of the test box (MIPT_FORCE_RCCL=1): RCCL is
+    opened, a communicator is made and the reduce runs on the library's stream; the image is the one the plain path gives."""
+    from cuda_path_tracer_amd import generators as G
+    from cuda_path_tracer_amd.scene import Scene, make_config
+    s = G.scene_icosphere_room(4).apply(Scene())
+    s.commit(devices=(0,))
+    cfg = make_config(160, 96, spp=3, cam_depth=4, light_depth=2)
+    plain, _ = s.render(cfg)
+    monkeypatch.setenv("MIPT_FORCE_RCCL", "1")
+    via_rccl, st = s.render(cfg)
+    again, _ = s.render(cfg)  # the communicator is kept between calls
+    assert np.array_equal(plain.view(np.uint32), via_rccl.view(np.uint32)) and np.array_equal(plain.view(np.uint32), again.view(np.uint32))
+    assert st["samples"] == 160 * 96 * 3
