@@ -4,7 +4,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmipt.so")
+LIB_PATH = os.environ.get("MIPT_LIB") or os.path.join(_HERE, "libmipt.so")  # MIPT_LIB: a developer build (scripts/build_phase_stats.sh)
 
 
 class RenderConfig(C.Structure):
