@@ -13,7 +13,7 @@ refuses to run with fewer than N visible devices and never reports n_gpus != N.
 
 Extra objects on the JSON line:
   roofline     dominant kernel k_extend (kd closest hit), three views that each are a fraction of a real limit:
-               `hbm`   memory-side bytes (L2 misses x 128 B + writes, rocprofv3 --pmc passes run by this script in
+               `hbm`   memory-side bytes (L2 misses x 128 B, reads and writes; rocprofv3 --pmc passes run by this script in
                        child processes before the timed part; calibration: profiles/r2_gather_calibration.txt) / launch
                        time (HIP events) vs 8 TB/s;  `valu`  VALU busy fraction and lane use from the same passes;
                `algorithmic` what the production kernel reads by its own layout (counted by k_extend<kCountWork> in an
@@ -146,9 +146,11 @@ def roofline_views(pmc, launch_ms, rays_per_launch, alg_bpr, ref_bpr, extra=None
         return r
     # the PMC passes ran a launch of the same shape; scale their per-launch counters to this launch by ray count
     scale = rays_per_launch / max(1.0, pmc["rays"] / max(1, pmc["launches"]))
-    miss_bytes = pmc["TCC_MISS_sum"] * LINE_BYTES * scale
+    # TCC_MISS counts read AND write misses (streaming writes all miss): on k_shade, which writes as much as it reads,
+    # FETCH_SIZE x 2 + WRITE_SIZE = 19.2 GB and TCC_MISS x 128 B = 19.4 GB per launch (profiles/r2_pmc_shading_kernels.txt)
+    # -- so the lines out of L2 are the whole memory-side traffic; WRITE_SIZE is reported beside it, not added to it.
     write_bytes = pmc["WRITE_SIZE"] * 1024.0 * scale
-    traffic = miss_bytes + write_bytes
+    traffic = pmc["TCC_MISS_sum"] * LINE_BYTES * scale
     hbm_gbs = traffic / sec / 1e9
     busy = 4.0 * pmc["SQ_ACTIVE_INST_VALU"] / (pmc["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0)
     lane = pmc["SQ_THREAD_CYCLES_VALU"] / (64.0 * pmc["SQ_ACTIVE_INST_VALU"])
@@ -156,15 +158,15 @@ def roofline_views(pmc, launch_ms, rays_per_launch, alg_bpr, ref_bpr, extra=None
                 "frac_of_measured_copy_peak": round(hbm_gbs / HBM_MEASURED_COPY_GBS, 4),
                 "bytes_per_ray": round(traffic / rays_per_launch, 1),
                 "l2_hit_rate": round(pmc["TCC_HIT_sum"] / max(1.0, pmc["TCC_HIT_sum"] + pmc["TCC_MISS_sum"]), 4),
-                "fetch_size_x2_bytes": int(round(pmc["FETCH_SIZE"] * 1024.0 * 2.0 * scale)),
-                "note": "L2 misses x 128 B + WRITE_SIZE per launch / HIP-event launch time; Infinity Cache hits are included "
+                "fetch_size_x2_bytes": int(round(pmc["FETCH_SIZE"] * 1024.0 * 2.0 * scale)), "write_size_bytes": int(round(write_bytes)),
+                "note": "L2 misses (reads and writes) x 128 B per launch / HIP-event launch time; Infinity Cache hits are included "
                         "(the counters sit on the L2's memory side)"}
     r["valu"] = {"busy_frac": round(busy, 4), "lane_use": round(lane, 4), "useful_lane_frac": round(busy * lane, 4),
                  "note": "busy = 4 x SQ_ACTIVE_INST_VALU / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs); lane use = SQ_THREAD_CYCLES_VALU / "
                          "(64 x SQ_ACTIVE_INST_VALU)"}
     r["algorithmic"]["memory_side_over_algorithmic"] = round(traffic / max(1.0, alg_bytes), 4)
     r["traffic"] = int(round(traffic))
-    r["traffic_unit"] = "bytes per launch (TCC_MISS_sum x 128 + WRITE_SIZE)"
+    r["traffic_unit"] = "bytes per launch (TCC_MISS_sum x 128 B: read and write misses of L2)"
     # which resource binds: the VALU issue slots (busy) or the memory side (against the ~6.3 TB/s a copy achieves).  The
     # fraction reported for a VALU-bound kernel is USEFUL lane throughput / peak lane throughput = busy x lane use: an
     # issue slot spent on a wave with most lanes masked off is not progress.

@@ -5,7 +5,7 @@ mkdir -p gpurun_out/pmc_shade
 i=0
 for ctrs in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_THREAD_CYCLES_VALU SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_INSTS_LDS" "GRBM_GUI_ACTIVE" "TCC_HIT_sum TCC_MISS_sum"; do
   i=$((i+1))
-  timeout -s KILL 240 rocprofv3 --pmc $ctrs --output-format csv -d gpurun_out/pmc_shade/p$i -- python bench.py --steps 1 --warmup 0 --no-closest --no-cpu-baseline > gpurun_out/pmc_shade/p$i.log 2>&1 || echo "pass $i failed"
+  timeout -s KILL 240 rocprofv3 --pmc $ctrs --output-format csv -d gpurun_out/pmc_shade/p$i -- python bench.py --steps 1 --warmup 0 --no-closest --no-cpu-baseline --no-pmc > gpurun_out/pmc_shade/p$i.log 2>&1 || echo "pass $i failed"
 done
 python - <<'PY'
 import csv, glob
