@@ -55,13 +55,14 @@ struct EventPool {
 
 // Scheduling knobs of the persistent extend kernel (wave-uniform kernel arguments; MIPT_TUNE="refill,batch,cap").
 struct ExtendTuning {
-    int refill_lanes = 32;      // refill a wave once this many lanes are idle (or all of them)
-    int leaf_batch_lanes = 28;  // scan leaves once this many lanes wait at one (or fewer lanes than this still traverse)
+    int refill_lanes = 16;      // refill a wave once this many lanes are idle (or all of them)
+    int leaf_batch_lanes = 16;  // scan leaves once this many lanes wait at one (or fewer lanes than this still traverse)
     int step_cap = 4;           // node steps per lane per round before lanes re-converge
     int pool1_below = 40;       // fewer lanes than this waiting at a leaf: the sphere pass is pooled over the wave too (kernels_extend.h)
     int common_origin = 0;      // per launch: 0 = rays carry their origins, 1 = all start at the eye, 2 = all start at lights[0]
     int n_heads = 8;            // ray cursors of the launch (8: one per XCD; 1: a single word, for A/B timing -- MIPT_HEADS)
-    // (defaults from the sweeps of scripts/tune.sh on MI355X; the optimum is flat within ~3 % around them)
+    // (defaults from the sweeps of scripts/tune_closest.py on MI355X; the optimum is flat within ~1 % around them.  With the
+    //  leaf scan pooled over the wave a scan is cheap at any count, so lanes wait less: round 1 shipped 32 / 28)
 };
 
 // Layout of DeviceCtx::counters (bytes): what mipt_trace_closest* uses outside a wavefront pass.
@@ -84,7 +85,7 @@ struct DeviceCtx {
     // MIPT_TUNE_COHERENT: queues in a coherent order (primary rays, binned shadow / light rays).  Their lanes finish
     // together, so refilling only when nearly the whole wave is idle keeps neighbouring rays in one wave: +3.5 % on the
     // 1080p box-room frame over refilling at 32 (40 / 48 / 56 / 60 / 64 idle lanes: 640 / 647 / 652 / 653 / 651 Msamples/s).
-    ExtendTuning tune_coherent = {60, 28, 4};
+    ExtendTuning tune_coherent = {60, 16, 4};
     int n_heads = 8;               // MIPT_HEADS=1|8: ray cursors per launch of the persistent kernel
     bool extend_simple = false;    // MIPT_EXTEND=simple: grid-stride reference kernel (A/B timing)
     int shadow_sort_from = 1;      // MIPT_SHADOW_SORT=<vertex>: first camera vertex whose shadow rays are binned by direction (-1: never)
