@@ -303,6 +303,8 @@ public:
         long hh = 0, ww = 0;
         if (sscanf(line, "-Y %ld +X %ld", &hh, &ww) != 2) return fail("unsupported orientation (only -Y h +X w, HDRLoader.cu:68)");
         if (ww <= 0 || hh <= 0 || ww > 0x7fff || hh > 0x7fff) return fail("resolution out of range (1..32767)");
+        // run-length coding packs at most 127 texels of one component into 2 bytes: 16 texels per byte of file at best
+        if ((size_t)ww * (size_t)hh > 16 * (n_ - at_) + 16) return fail("resolution larger than the file can hold");
         w = (int)ww;
         h = (int)hh;
         return true;
