@@ -303,8 +303,9 @@ public:
         long hh = 0, ww = 0;
         if (sscanf(line, "-Y %ld +X %ld", &hh, &ww) != 2) return fail("unsupported orientation (only -Y h +X w, HDRLoader.cu:68)");
         if (ww <= 0 || hh <= 0 || ww > 0x7fff || hh > 0x7fff) return fail("resolution out of range (1..32767)");
-        // run-length coding packs at most 127 texels of one component into 2 bytes: 16 texels per byte of file at best
-        if ((size_t)ww * (size_t)hh > 16 * (n_ - at_) + 16) return fail("resolution larger than the file can hold");
+        // every scanline takes at least four bytes of the file (a flat texel, or the run-length prefix); its WIDTH is not
+        // bounded by the file's size: three (1,1,1,n) markers behind one texel repeat it up to 255 + 255 * 256 + ... times
+        if ((size_t)hh > (n_ - at_) / 4) return fail("more scanlines than the file can hold");
         w = (int)ww;
         h = (int)hh;
         return true;
@@ -379,12 +380,14 @@ bool load_hdr_rgbe(const char *path, int &w, int &h, std::vector<uint32_t> &texe
     if (!file.open(path)) { err = std::string("cannot open HDR file ") + path; return false; }
     RadianceReader rd(reinterpret_cast<const unsigned char *>(file.data), file.size);
     if (!rd.header(w, h)) { err = std::string(path) + ": " + rd.error(); return false; }
-    texels.assign((size_t)w * h, 0u);
-    for (int y = 0; y < h; y++)  // rows stay in file order: top row first (HDRLoader.cu:86-91)
+    texels.clear();
+    for (int y = 0; y < h; y++) {  // rows stay in file order: top row first (HDRLoader.cu:86-91)
+        texels.resize((size_t)(y + 1) * w, 0u);  // grown row by row: a damaged header cannot ask for memory the rows never fill
         if (!rd.scanline(texels.data() + (size_t)y * w, w)) {
             err = std::string(path) + ": row " + std::to_string(y) + ": " + rd.error();
             return false;
         }
+    }
     return true;
 }
 

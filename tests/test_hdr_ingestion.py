@@ -52,7 +52,7 @@ def _rle_row(w, comps):
     (HEAD + b"+X 8 -Y 8\n", "orientation"),
     (HEAD + b"-Y 0 +X 8\n", "range"),
     (HEAD + b"-Y 1 +X 40000\n", "range"),
-    (HEAD + b"-Y 30000 +X 30000\n" + bytes(64), "larger than the file"),                        # no 3.6 GB allocation for a 100-byte file
+    (HEAD + b"-Y 30000 +X 30000\n" + bytes(64), "more scanlines than the file"),                 # no 3.6 GB allocation for a 100-byte file
     (HEAD + b"-Y 2 +X 8\n" + bytes(32), "truncated scanline"),                                   # second flat row missing
     (HEAD + b"-Y 1 +X 8\n" + bytes([1, 1, 1, 4]) + bytes(28), "repeat marker before"),
     (HEAD + b"-Y 1 +X 8\n" + bytes([5, 5, 5, 128, 1, 1, 1, 9]), "repeat leaves"),
