@@ -234,7 +234,7 @@ __global__ __launch_bounds__(kExtendBlock, 5) void k_extend(DScene sc, const f4 
     int head = n_heads == 1 ? 0 : (int)(blockIdx.x & 7u);
     int heads_dry = 0;
     WorkCounters wc = {0u, 0u, 0u, 0u, 0u, 0u};
-    const int root0 = sc.n_meshes > 0 ? sc.meshes[0].root : 0;  // wave-uniform: one link less in a fresh ray's load chain
+    const int root0 = sc.n_meshes > 0 ? ldk_i32(&sc.meshes[0].root) : 0;  // wave-uniform: one link less in a fresh ray's load chain
     TravCounters tc = {0u, 0u, 0u, 0u, 0u};
     unsigned int hit_tris = 0;
 #ifdef MIPT_PHASE_STATS
@@ -322,7 +322,7 @@ __global__ __launch_bounds__(kExtendBlock, 5) void k_extend(DScene sc, const f4 
                     } else if (tune.common_origin == 1) {
                         o = mk3(sc.cam_eye[0], sc.cam_eye[1], sc.cam_eye[2]);
                     } else {
-                        const f4 l0 = sc.lights[0];
+                        const f4 l0 = ldk4(sc.lights, 0);
                         o = mk3(l0.x, l0.y, l0.z);
                     }
                     d = mk3(d4.x, d4.y, d4.z);

@@ -12,7 +12,7 @@
 //                               streams these 16-byte records and touches vertices only for survivors
 //   tri_pos  float4[3*n_tris]   vertex positions a,b,c (w unused) -- three 16-byte loads per candidate
 //   tri_nrm  float4[3*n_tris]   vertex normals, fetched once for the winning triangle
-//   meshes / spheres / planes / lights / materials: small tables read through scalar loads
+//   meshes / spheres / planes / lights / materials: small tables; wave-uniform reads go through ldk4() below
 //   env      6 cube faces, raw RGBE (4 B/texel) or fp32 RGB
 #pragma once
 #include <stdint.h>
@@ -59,6 +59,26 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 struct alignas(32) SpherePair {
     v2f x, y, z, r2;
 };
+
+// Loads from the scene's small read-only tables (planes, spheres, lights, mesh roots and their cull boxes).  The arena is
+// never written while a kernel runs, so on the device these go through the CONSTANT address space: a wave-uniform
+// address becomes a scalar load (s_load_dwordx4/x8 into SGPRs through the scalar data cache, no VGPRs, hoistable out of
+// loops) instead of a vector load per lane of the same 16 bytes followed by a wait on the vector-memory counter; a
+// divergent address still compiles to an ordinary vector load.
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef const float __attribute__((address_space(4))) *kfloat_p;
+typedef const int32_t __attribute__((address_space(4))) *kint_p;
+PT_HD f4 ldk4(const f4 *base, size_t idx) {
+    kfloat_p p = (kfloat_p)(uintptr_t)(base + idx);
+    f4 r;
+    r.x = p[0]; r.y = p[1]; r.z = p[2]; r.w = p[3];
+    return r;
+}
+PT_HD int32_t ldk_i32(const int32_t *p) { return *(kint_p)(uintptr_t)p; }
+#else
+PT_HD f4 ldk4(const f4 *base, size_t idx) { return base[idx]; }
+PT_HD int32_t ldk_i32(const int32_t *p) { return *p; }
+#endif
 
 // Device view of the packed scene; passed to kernels by value (kernarg -> scalar loads).
 struct DScene {

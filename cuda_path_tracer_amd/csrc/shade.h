@@ -87,7 +87,7 @@ PT_HD Surface surface_at(const DScene &sc, f3 o, f3 d, float t, int prim) {
         s.nrm = norm3(xyz(na) * b0 + xyz(nb) * b2 + xyz(nc) * b1);
         int m = 0;
         for (int k = 1; k < sc.n_meshes; k++)
-            if (prim >= sc.meshes[k].tri_base) m = k;
+            if (prim >= ldk_i32(&sc.meshes[k].tri_base)) m = k;
         mat = sc.meshes[m].material;
     } else if (prim < sc.total_tris + sc.n_spheres) {
         const int i = prim - sc.total_tris;
@@ -107,7 +107,7 @@ PT_HD Surface surface_at(const DScene &sc, f3 o, f3 d, float t, int prim) {
 }
 
 PT_HD f3 radiance_at(const DScene &sc, int light, f3 p) {
-    const f3 loc = xyz(sc.lights[2 * light]), power = xyz(sc.lights[2 * light + 1]);
+    const f3 loc = xyz(ldk4(sc.lights, 2 * (size_t)light)), power = xyz(ldk4(sc.lights, 2 * (size_t)light + 1));
     float d2 = dot3(loc - p, loc - p);
     if (d2 < kEps) d2 = kEps;
     return power / d2 / 4.0f / kPi;

@@ -583,24 +583,47 @@ PT_HD void quadrics_closest(const DScene &sc, f3 o, f3 d, float &out_t, int &out
     float best = -1.0f;
     int prim = -1;
     for (int i = 0; i < sc.n_spheres; i++) {
-        const f4 s = sc.spheres[2 * i];
+        const f4 s = ldk4(sc.spheres, 2 * (size_t)i);
         const float t = sphere_t(mk3(s.x, s.y, s.z), s.w, o, d);
         if (t > 0.0f && (best < 0.0f || t < best)) { best = t; prim = sc.total_tris + i; }
     }
     for (int i = 0; i < sc.n_planes; i++) {
-        const f4 p = sc.planes[2 * i], n = sc.planes[2 * i + 1];
+        const f4 p = ldk4(sc.planes, 2 * (size_t)i), n = ldk4(sc.planes, 2 * (size_t)i + 1);
         const float t = plane_t(mk3(p.x, p.y, p.z), mk3(n.x, n.y, n.z), o, d);
         if (t > 0.0f && (best < 0.0f || t < best)) { best = t; prim = sc.total_tris + sc.n_spheres + i; }
     }
     out_t = best;
     out_prim = prim;
 }
+// The same for two rays at once (k_shade: the next camera ray and the direct connection of a vertex): every table entry
+// is fetched once, and the two rays' tests are independent instruction streams.
+PT_HD void quadrics_closest2(const DScene &sc, f3 o1, f3 d1, f3 o2, f3 d2, float &out_t1, int &out_prim1, float &out_t2,
+                             int &out_prim2) {
+    float best1 = -1.0f, best2 = -1.0f;
+    int prim1 = -1, prim2 = -1;
+    for (int i = 0; i < sc.n_spheres; i++) {
+        const f4 s = ldk4(sc.spheres, 2 * (size_t)i);
+        const float t1 = sphere_t(mk3(s.x, s.y, s.z), s.w, o1, d1), t2 = sphere_t(mk3(s.x, s.y, s.z), s.w, o2, d2);
+        if (t1 > 0.0f && (best1 < 0.0f || t1 < best1)) { best1 = t1; prim1 = sc.total_tris + i; }
+        if (t2 > 0.0f && (best2 < 0.0f || t2 < best2)) { best2 = t2; prim2 = sc.total_tris + i; }
+    }
+    for (int i = 0; i < sc.n_planes; i++) {
+        const f4 p = ldk4(sc.planes, 2 * (size_t)i), n = ldk4(sc.planes, 2 * (size_t)i + 1);
+        const float t1 = plane_t(mk3(p.x, p.y, p.z), mk3(n.x, n.y, n.z), o1, d1), t2 = plane_t(mk3(p.x, p.y, p.z), mk3(n.x, n.y, n.z), o2, d2);
+        if (t1 > 0.0f && (best1 < 0.0f || t1 < best1)) { best1 = t1; prim1 = sc.total_tris + sc.n_spheres + i; }
+        if (t2 > 0.0f && (best2 < 0.0f || t2 < best2)) { best2 = t2; prim2 = sc.total_tris + sc.n_spheres + i; }
+    }
+    out_t1 = best1; out_prim1 = prim1;
+    out_t2 = best2; out_prim2 = prim2;
+}
 // A ray that misses the root CULL box of every mesh cannot be given a mesh hit by the reference (an accepted hit lies
 // inside it, see box_culled): the parked sphere / plane answer is final and the ray never reaches the (divergent)
 // extend kernel -- which applies the reference's own root test (mesh.cuh:254) to the rest.  No IEEE division here.
 PT_HD bool misses_every_mesh(const DScene &sc, f3 o, f3 d) {
-    for (int m = 0; m < sc.n_meshes; m++)
-        if (!leaf_culled(sc, sc.meshes[m].root, o, d)) return false;
+    for (int m = 0; m < sc.n_meshes; m++) {
+        const size_t root = (size_t)ldk_i32(&sc.meshes[m].root);
+        if (!box_culled(ldk4(sc.tight, 2 * root), ldk4(sc.tight, 2 * root + 1), o, d)) return false;
+    }
     return true;
 }
 

@@ -455,7 +455,7 @@ __global__ __launch_bounds__(kBlock) void k_shade(DScene sc, PassParams pp, WfBu
                 const Surface s = surface_at(sc, o, d, h.t, h.prim);
                 const size_t sbase = (size_t)j * pp.K;
                 {  // direct connection to lights[0] (Q13); the shadow ray starts AT the light (Q10)
-                    const f3 lp = xyz(sc.lights[0]);
+                    const f3 lp = xyz(ldk4(sc.lights, 0));
                     const f3 ld = norm3(s.pos - lp);
                     const float ct = dot3(s.nrm, neg3(ld));
                     if (ct > kEps) {
@@ -526,19 +526,23 @@ __global__ __launch_bounds__(kBlock) void k_shade(DScene sc, PassParams pp, WfBu
             // the two rays this vertex makes: the next camera ray and the direct connection.  Their sphere / plane
             // answers are taken here (convergent lanes); a ray that misses every mesh's root cull box is finished
             // (52 % of them in the box-room scenes), the others are queued for the extend kernel.
-            const f3 lp = xyz(sc.lights[0]);
+            const f3 lp = xyz(ldk4(sc.lights, 0));
             const size_t si = (size_t)j * pp.K;
             HitRec ch, sh;
             ch.t = sh.t = -1.0f;
             ch.prim = sh.prim = -1;
             bool cam_extend = false, need_extend = false;
-            if (cont) {
-                quadrics_closest(sc, nro, nrd, ch.t, ch.prim);
-                cam_extend = !misses_every_mesh(sc, nro, nrd);
-            }
-            if (direct) {
-                quadrics_closest(sc, lp, dr_d, sh.t, sh.prim);
-                need_extend = !misses_every_mesh(sc, lp, dr_d);
+            {   // (evaluated on every lane: a lane without one of the two rays works on a placeholder and drops the answer)
+                HitRec c2, s2;
+                quadrics_closest2(sc, nro, nrd, lp, dr_d, c2.t, c2.prim, s2.t, s2.prim);
+                if (cont) {
+                    ch = c2;
+                    cam_extend = !misses_every_mesh(sc, nro, nrd);
+                }
+                if (direct) {
+                    sh = s2;
+                    need_extend = !misses_every_mesh(sc, lp, dr_d);
+                }
             }
             // a continuing path takes its rank among the block's continuing paths as its index at the next vertex
             const Idx3 at = block_append3(cont, cam_extend, need_extend, &b.counts[kCntPad * (kCntCam + i + 1)],
@@ -603,7 +607,7 @@ __global__ __launch_bounds__(kBlock) void k_shade(DScene sc, PassParams pp, WfBu
 __global__ __launch_bounds__(kBlock) void k_resolve(DScene sc, PassParams pp, WfBuffers b, int i) {
     const int n = b.counts[kCntPad * (kCntCam + i)];
     const bool by_id = (i == 0) && (pp.Dl != 0);
-    const f3 lp = xyz(sc.lights[0]);
+    const f3 lp = xyz(ldk4(sc.lights, 0));
     for (int idx = blockIdx.x * kBlock + threadIdx.x; idx < n; idx += gridDim.x * kBlock) {
         const int j = by_id ? b.q_cam0[idx] : idx;
         const uint32_t mask = b.sh_mask[j];
@@ -641,7 +645,7 @@ __global__ __launch_bounds__(kBlock) void k_resolve(DScene sc, PassParams pp, Wf
 // whose connection was answered on the spot.
 __global__ __launch_bounds__(kBlock) void k_resolve_queue(DScene sc, WfBuffers b, int i) {
     const int n = b.counts[kCntPad * (kCntShadow + i)];
-    const f3 lp = xyz(sc.lights[0]);
+    const f3 lp = xyz(ldk4(sc.lights, 0));
     for (int idx = blockIdx.x * kBlock + threadIdx.x; idx < n; idx += gridDim.x * kBlock) {
         const int si = b.q_shadow[idx];
         const HitRec h = b.sh_hit[si];
