@@ -144,7 +144,11 @@ int setup_device(mipt_scene *s, DeviceCtx &dc) {
         sscanf(tv, "%d,%d,%d,%d", &dc.tune_coherent.refill_lanes, &dc.tune_coherent.leaf_batch_lanes, &dc.tune_coherent.step_cap,
                &dc.tune_coherent.pool1_below);
     clamp_tuning(dc.tune);
+    if (const char *tv = getenv("MIPT_TUNE_BATCH_COHERENT"))
+        sscanf(tv, "%d,%d,%d,%d", &dc.tune_batch_coherent.refill_lanes, &dc.tune_batch_coherent.leaf_batch_lanes,
+               &dc.tune_batch_coherent.step_cap, &dc.tune_batch_coherent.pool1_below);
     clamp_tuning(dc.tune_coherent);
+    clamp_tuning(dc.tune_batch_coherent);
     dc.view = s->host.view(dc.arena);
     return 0;
 }
@@ -373,11 +377,12 @@ int mipt_trace_closest_device(mipt_scene *s, int slot, const float *d_ray_o, con
     HIP_TRY(hipMemsetAsync(dc.counters.p, 0, kCounterBytes, dc.stream));
     const int blocks = (int)((n + 255) / 256);
     HIP_TRY(hipEventRecord(e0, dc.stream));
+    int *probe = reinterpret_cast<int *>(dc.counters.as<char>() + kCtrProbe);
     hipLaunchKernelGGL(k_make_rays, dim3(blocks), dim3(256), 0, dc.stream, dc.view, d_ray_o, d_ray_d, n, dc.ray_o.as<f4>(),
-                       dc.ray_d.as<f4>(), dc.hits.as<HitRec>());
+                       dc.ray_d.as<f4>(), dc.hits.as<HitRec>(), probe);
     HIP_TRY(hipEventRecord(e1, dc.stream));
     launch_extend(dc, mode, dc.ray_o.as<f4>(), dc.ray_d.as<f4>(), nullptr, nullptr, (int)n, n, dc.hits.as<HitRec>(),
-                  reinterpret_cast<int *>(dc.counters.as<char>() + kCtrCursor), dc.counters.as<unsigned long long>());
+                  reinterpret_cast<int *>(dc.counters.as<char>() + kCtrCursor), dc.counters.as<unsigned long long>(), false, 0, probe);
     HIP_TRY(hipEventRecord(e2, dc.stream));
     hipLaunchKernelGGL(k_split_hits, dim3(blocks), dim3(256), 0, dc.stream, dc.hits.as<HitRec>(), n, d_prim, d_t);
     HIP_TRY(hipEventRecord(e3, dc.stream));
@@ -420,9 +425,10 @@ int mipt_trace_closest_device_noalloc(mipt_scene *s, int slot, const float *d_ra
     HIP_TRY(wait_for_caller(dc));
     HIP_TRY(hipMemsetAsync(base, 0, kNoAllocHead, dc.stream));  // the cursors must start at zero; the rest is overwritten
     const int blocks = (int)((n + 255) / 256);
-    hipLaunchKernelGGL(k_make_rays, dim3(blocks), dim3(256), 0, dc.stream, dc.view, d_ray_o, d_ray_d, n, ro, rd, hits);
+    int *probe = reinterpret_cast<int *>(base + 8 * 256 + kCtrProbe);  // (inside the zeroed head of the scratch)
+    hipLaunchKernelGGL(k_make_rays, dim3(blocks), dim3(256), 0, dc.stream, dc.view, d_ray_o, d_ray_d, n, ro, rd, hits, probe);
     launch_extend(dc, kProd, ro, rd, nullptr, nullptr, (int)n, n, hits, reinterpret_cast<int *>(base),
-                  reinterpret_cast<unsigned long long *>(base + 8 * 256));
+                  reinterpret_cast<unsigned long long *>(base + 8 * 256), false, 0, probe);
     hipLaunchKernelGGL(k_split_hits, dim3(blocks), dim3(256), 0, dc.stream, hits, n, d_prim, d_t);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(dc.stream));

@@ -69,6 +69,7 @@ struct ExtendTuning {
 constexpr size_t kCtrRef = 0;        // 8 x u64: counters of the reference walk (k_extend<kCountRef>)
 constexpr size_t kCtrPhase = 128;    // 24 x u64: developer build, per-phase lane use
 constexpr size_t kCtrWork = 320;     // 8 x u64: what the production kernel read (k_extend<kCountWork>)
+constexpr size_t kCtrProbe = 384;    // 2 x int: coherence probe of a closest-hit batch (k_make_rays): waves sampled, waves found coherent
 constexpr size_t kCtrCursor = 1024;  // 8 ray cursors of the persistent kernel, 256 B apart (one per XCD)
 constexpr size_t kCounterBytes = kCtrCursor + 8 * 256;
 
@@ -86,6 +87,11 @@ struct DeviceCtx {
     // together, so refilling only when nearly the whole wave is idle keeps neighbouring rays in one wave: +3.5 % on the
     // 1080p box-room frame over refilling at 32 (40 / 48 / 56 / 60 / 64 idle lanes: 640 / 647 / 652 / 653 / 651 Msamples/s).
     ExtendTuning tune_coherent = {60, 16, 4};
+    // MIPT_TUNE_BATCH_COHERENT: mipt_trace_closest* batches whose rays turn out to arrive in a coherent order (k_make_rays
+    // samples one wave in 256: common origin, directions within a narrow cone) -- chosen by the kernel itself from the
+    // probe's two counters, no host round trip.  1.31 M triangles, 2^24 camera rays: 16 / 32 / 48 / 60 idle lanes ->
+    // 3358 / 3471 / 3640 / 3547 Mrays/s; the same settings cost an incoherent batch 3 ... 19 %.
+    ExtendTuning tune_batch_coherent = {48, 16, 4};
     int n_heads = 8;               // MIPT_HEADS=1|8: ray cursors per launch of the persistent kernel
     bool extend_simple = false;    // MIPT_EXTEND=simple: grid-stride reference kernel (A/B timing)
     int shadow_sort_from = 1;      // MIPT_SHADOW_SORT=<vertex>: first camera vertex whose shadow rays are binned by direction (-1: never)

@@ -219,8 +219,18 @@ __global__ __launch_bounds__(kExtendBlock, 5) void k_extend(DScene sc, const f4 
                                                          const f4 *__restrict__ ray_d, const int *__restrict__ queue,
                                                          const int *__restrict__ count_ptr, int n_fixed,
                                                          HitRec *__restrict__ hits, int *__restrict__ work,
-                                                         unsigned long long *ctr, ExtendTuning tune) {
+                                                         unsigned long long *ctr, ExtendTuning tune, ExtendTuning tune_if_coherent,
+                                                         const int *__restrict__ probe) {
     constexpr bool COUNT = MODE == kCountRef;
+    if (probe) {  // closest-hit batch: k_make_rays sampled the order the rays arrive in (wave-uniform choice)
+        const int sampled = probe[0], coherent = probe[1];
+        if (sampled > 0 && 10 * (long long)coherent >= 9 * (long long)sampled) {
+            tune.refill_lanes = tune_if_coherent.refill_lanes;
+            tune.leaf_batch_lanes = tune_if_coherent.leaf_batch_lanes;
+            tune.step_cap = tune_if_coherent.step_cap;
+            tune.pool1_below = tune_if_coherent.pool1_below;
+        }
+    }
     constexpr bool WORK = MODE == kCountWork;
     __shared__ int stack_mem[kStackDepth * kExtendBlock];
     __shared__ int coop_items[(kExtendBlock / 64) * 2 * kCoopItems];
@@ -502,18 +512,40 @@ __global__ __launch_bounds__(kExtendBlock) void k_extend_simple(DScene sc, const
 
 // Ray(o, d) constructor (ray.cuh:10): dir = d * (1/(|d|+eps)).  Packed xyz triples -> float4 pairs; the sphere / plane
 // answer of each ray is parked in its hit slot (see quadrics_closest).
+// Coherence probe (probe != null): the first wave of every 64th block, when all its 64 rays exist, looks at the spread of
+// its rays -- origins within 5 % of their magnitude (+1), directions within 0.25 per component: a bundle like 64
+// neighbouring camera rays -- and counts itself in probe[0], and in probe[1] if coherent.  The extend kernel picks its
+// scheduling thresholds from the two counts (a choice that changes no result).
+__device__ __forceinline__ float wave_max_f(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+    return v;
+}
 static __global__ __launch_bounds__(256) void k_make_rays(DScene sc, const float *__restrict__ o3, const float *__restrict__ d3,
                                                           int64_t n, f4 *__restrict__ ray_o, f4 *__restrict__ ray_d,
-                                                          HitRec *__restrict__ hits) {
+                                                          HitRec *__restrict__ hits, int *__restrict__ probe) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    const f3 o = mk3(o3[3 * i], o3[3 * i + 1], o3[3 * i + 2]);
-    const f3 d = norm3(mk3(d3[3 * i], d3[3 * i + 1], d3[3 * i + 2]));
-    ray_o[i] = f4{o.x, o.y, o.z, 0.f};
-    ray_d[i] = f4{d.x, d.y, d.z, 0.f};
-    HitRec h;
-    quadrics_closest(sc, o, d, h.t, h.prim);
-    hits[i] = h;
+    const bool live = i < n;
+    f3 o = mk3(0.f, 0.f, 0.f), d = mk3(0.f, 0.f, 1.f);
+    if (live) {
+        o = mk3(o3[3 * i], o3[3 * i + 1], o3[3 * i + 2]);
+        d = norm3(mk3(d3[3 * i], d3[3 * i + 1], d3[3 * i + 2]));
+        ray_o[i] = f4{o.x, o.y, o.z, 0.f};
+        ray_d[i] = f4{d.x, d.y, d.z, 0.f};
+        HitRec h;
+        quadrics_closest(sc, o, d, h.t, h.prim);
+        hits[i] = h;
+    }
+    if (probe && (blockIdx.x & 63u) == 0u && threadIdx.x < 64u && __ballot(live) == ~0ull) {
+        // spread of each component = max + max of the negated values; NaN rays compare false below: not coherent
+        const float so = fmaxf(fmaxf(wave_max_f(o.x) + wave_max_f(-o.x), wave_max_f(o.y) + wave_max_f(-o.y)), wave_max_f(o.z) + wave_max_f(-o.z));
+        const float sd = fmaxf(fmaxf(wave_max_f(d.x) + wave_max_f(-d.x), wave_max_f(d.y) + wave_max_f(-d.y)), wave_max_f(d.z) + wave_max_f(-d.z));
+        const float mo = wave_max_f(fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fabsf(o.z)));
+        if (threadIdx.x == 0) {
+            atomicAdd(&probe[0], 1);
+            if (so <= 0.05f * (mo + 1.0f) && sd <= 0.25f) atomicAdd(&probe[1], 1);
+        }
+    }
 }
 
 static __global__ __launch_bounds__(256) void k_split_hits(const HitRec *__restrict__ hits, int64_t n,
@@ -529,7 +561,7 @@ static __global__ __launch_bounds__(256) void k_split_hits(const HitRec *__restr
 // ray cursors).  mode: kProd / kCountRef / kCountWork.
 inline void launch_extend(const DeviceCtx &dc, int mode, const f4 *ro, const f4 *rd, const int *queue, const int *count_ptr,
                           int n_fixed, int64_t n_max, HitRec *hits, int *work, unsigned long long *ctr, bool coherent_queue = false,
-                          int common_origin = 0) {  // (common_origin != 0: persistent kernel only)
+                          int common_origin = 0, const int *probe = nullptr) {  // (common_origin != 0, probe: persistent kernel only)
     ExtendTuning tune = coherent_queue ? dc.tune_coherent : dc.tune;
     tune.common_origin = common_origin;
     tune.n_heads = dc.n_heads;
@@ -549,13 +581,13 @@ inline void launch_extend(const DeviceCtx &dc, int mode, const f4 *ro, const f4 
     const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(want, (int64_t)dc.num_cus * dc.extend_blocks_per_cu));
     if (mode == kCountRef)
         hipLaunchKernelGGL(k_extend<kCountRef>, dim3(grid), dim3(kExtendBlock), 0, dc.stream, dc.view, ro, rd, queue, count_ptr,
-                           n_fixed, hits, work, ctr, tune);
+                           n_fixed, hits, work, ctr, tune, dc.tune_batch_coherent, probe);
     else if (mode == kCountWork)
         hipLaunchKernelGGL(k_extend<kCountWork>, dim3(grid), dim3(kExtendBlock), 0, dc.stream, dc.view, ro, rd, queue, count_ptr,
-                           n_fixed, hits, work, ctr, tune);
+                           n_fixed, hits, work, ctr, tune, dc.tune_batch_coherent, probe);
     else
         hipLaunchKernelGGL(k_extend<kProd>, dim3(grid), dim3(kExtendBlock), 0, dc.stream, dc.view, ro, rd, queue, count_ptr,
-                           n_fixed, hits, work, ctr, tune);
+                           n_fixed, hits, work, ctr, tune, dc.tune_batch_coherent, probe);
 }
 
 // Resident 256-thread blocks per CU of the persistent kernel (occupancy API, capped like the hardware admits).

@@ -171,3 +171,17 @@ def test_leaf_scan_pooling_modes_change_no_result(tune, monkeypatch):
     monkeypatch.setenv("MIPT_TUNE_COHERENT", tune)
     _check(G.scene_icosphere_room(5), 32768, lattice=10)
     _check(G.scene_multi_sphere(3), 16384)
+
+
+@pytest.mark.parametrize("alt", ["48,16,4,40", "64,64,1,65", "1,1,8,0"])
+def test_coherence_probe_changes_no_result(alt, monkeypatch):
+    """A batch that arrives in a coherent order (camera rays: k_make_rays' probe samples one wave in 256) makes the extend
+    kernel pick its alternative scheduling thresholds (MIPT_TUNE_BATCH_COHERENT) by itself; an incoherent batch keeps the
+    default ones.  Either way: the oracle's primitive and t, bit for bit."""
+    monkeypatch.setenv("MIPT_TUNE_BATCH_COHERENT", alt)
+    desc = G.scene_icosphere_room(5)
+    s, o = _pair(desc)
+    for ro, rd in (G.camera_rays(desc.camera, 512, 256, 131072), G.incoherent_rays(65536, (-3, -3.5, -4.5), (3, 1.5, 0.5))):
+        op, ot, _ = o.trace_closest(ro, rd)
+        gp, gt, _ = s.trace_closest(ro, rd)
+        _same(gp, gt, op, ot, "production kernel, tuning chosen by the probe")
