@@ -39,6 +39,14 @@ namespace mipt {
 namespace {
 
 constexpr int kBlock = 512;
+// streaming stores: written once, read once by a later kernel -- keep them from displacing the gathers' lines
+typedef float v4f_nt __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void st_nt(f4 *p, f4 v) { __builtin_nontemporal_store((v4f_nt){v.x, v.y, v.z, v.w}, reinterpret_cast<v4f_nt *>(p)); }
+__device__ __forceinline__ void st_nt(HitRec *p, HitRec v) {
+    typedef float v2f_nt __attribute__((ext_vector_type(2)));
+    __builtin_nontemporal_store((v2f_nt){v.t, as_f32((uint32_t)v.prim)}, reinterpret_cast<v2f_nt *>(p));
+}
+
 
 // ---- queue append: ballot + mbcnt rank inside a wave, LDS scan over the block's waves, ONE atomic per block ----
 // Same-address atomics complete at ~88 M/s on MI355X (scripts/micro/atomic_bench.hip): one per wave capped the
@@ -549,10 +557,10 @@ __global__ __launch_bounds__(kBlock) void k_shade(DScene sc, PassParams pp, WfBu
                                           &b.counts[kCntPad * (kCntExtCam + i + 1)], &b.counts[kCntPad * (kCntShadow + i)],
                                           ap3_lds, phase3);
             if (cont) {
-                b.st_o[par ^ 1][at.a] = mk4(nro, as_f32(draw));
-                b.st_d[par ^ 1][at.a] = mk4(nrd, as_f32((uint32_t)pid));
-                b.st_T[par ^ 1][at.a] = mk4(Tc, pc);
-                b.st_hit[par ^ 1][at.a] = ch;
+                st_nt(&b.st_o[par ^ 1][at.a], mk4(nro, as_f32(draw)));
+                st_nt(&b.st_d[par ^ 1][at.a], mk4(nrd, as_f32((uint32_t)pid)));
+                st_nt(&b.st_T[par ^ 1][at.a], mk4(Tc, pc));
+                st_nt(&b.st_hit[par ^ 1][at.a], ch);
             }
             if (cam_extend) b.q_ext_cam[at.b] = at.a;
             const int qi = at.c;
@@ -560,10 +568,10 @@ __global__ __launch_bounds__(kBlock) void k_shade(DScene sc, PassParams pp, WfBu
                 b.q_shadow[qi] = (int)si;
                 if (b.q_shadow_key) b.q_shadow_key[qi] = direction_cell(dr_d);
                 if (!pp.common_origins) b.sh_o[si] = mk4(lp, 0.f);
-                b.sh_d[si] = mk4(dr_d, 0.f);
-                b.sh_target[si] = mk4(dr_target, 0.f);
-                b.sh_contrib[si] = mk4(dr_contrib, as_f32((uint32_t)pid));
-                b.sh_hit[si] = sh;
+                st_nt(&b.sh_d[si], mk4(dr_d, 0.f));
+                st_nt(&b.sh_target[si], mk4(dr_target, 0.f));
+                st_nt(&b.sh_contrib[si], mk4(dr_contrib, as_f32((uint32_t)pid)));
+                st_nt(&b.sh_hit[si], sh);
                 mask |= 1u;
             } else if (direct) {
                 n_trivial++;
