@@ -535,7 +535,6 @@ __global__ __launch_bounds__(kBlock) void k_shade(DScene sc, PassParams pp, WfBu
             // answers are taken here (convergent lanes); a ray that misses every mesh's root cull box is finished
             // (52 % of them in the box-room scenes), the others are queued for the extend kernel.
             const f3 lp = xyz(ldk4(sc.lights, 0));
-            const size_t si = (size_t)j * pp.K;
             HitRec ch, sh;
             ch.t = sh.t = -1.0f;
             ch.prim = sh.prim = -1;
@@ -564,6 +563,10 @@ __global__ __launch_bounds__(kBlock) void k_shade(DScene sc, PassParams pp, WfBu
             }
             if (cam_extend) b.q_ext_cam[at.b] = at.a;
             const int qi = at.c;
+            // where the direct connection's record goes: with one shadow ray per path (simple integrator) at its RANK in the
+            // shadow queue -- the records of a block are one dense run of full lines, the queue is the identity and
+            // k_resolve_queue streams them; with connection rays besides (K > 1) in the path's slot group j * K
+            const size_t si = pp.K == 1 ? (size_t)qi : (size_t)j * pp.K;
             if (need_extend) {
                 b.q_shadow[qi] = (int)si;
                 if (b.q_shadow_key) b.q_shadow_key[qi] = direction_cell(dr_d);
@@ -655,7 +658,7 @@ __global__ __launch_bounds__(kBlock) void k_resolve_queue(DScene sc, WfBuffers b
     const int n = b.counts[kCntPad * (kCntShadow + i)];
     const f3 lp = xyz(ldk4(sc.lights, 0));
     for (int idx = blockIdx.x * kBlock + threadIdx.x; idx < n; idx += gridDim.x * kBlock) {
-        const int si = b.q_shadow[idx];
+        const int si = idx;  // K == 1: record index == queue rank (k_shade)
         const HitRec h = b.sh_hit[si];
         const f4 tg = b.sh_target[si];
         if (shadow_visible(lp, norm3(norm3(xyz(tg) - lp)), h.t, tg)) {
@@ -882,8 +885,10 @@ int wavefront_render(const HostScene &hs, DeviceCtx &dc, const mipt_render_confi
             const int *shadow_queue = b.q_shadow;
             if (sort_shadow && i >= dc.shadow_sort_from)
                 WF_TRY(sort_queue(b.q_shadow_key, b.q_shadow, kCntShadow + i, kShadowKeyBits, shadow_queue));
+            const bool binned = shadow_queue != b.q_shadow;
+            if (K == 1 && !binned) shadow_queue = nullptr;  // K == 1: the records sit at their queue rank, the unsorted queue is the identity
             extend(pp.common_origins ? nullptr : b.sh_o, b.sh_d, shadow_queue, &b.counts[kCntPad * (kCntShadow + i)], b.sh_hit, np * K,
-                   K == 1 && (i == 0 || shadow_queue != b.q_shadow),  // (K > 1: mostly connection rays, in path order)
+                   K == 1 && (i == 0 || binned),  // (K > 1: mostly connection rays, in path order)
                    pp.common_origins ? 2 : 0);
             if (K == 1) hipLaunchKernelGGL(k_resolve_queue, dim3(path_grid), dim3(kBlock), 0, sm, dc.view, b, i);
             else hipLaunchKernelGGL(k_resolve, dim3(path_grid), dim3(kBlock), 0, sm, dc.view, pp, b, i);
