@@ -323,20 +323,17 @@ PT_HD bool descend_fast(const DScene &sc, f3 o, f3 d, SlabBox &cur, int &node, K
         // the split plane's own point against the parent's bounds, then the one bound each child replaces
         const f3 P = ray_at(o, d, ts);
         const float Pc[3] = {P.x, P.y, P.z};
-        bool in_lo[3], in_hi[3];
-        in_lo[0] = cur.lo[0] <= Pc[0];
-        in_lo[1] = cur.lo[1] <= Pc[1] + kEps;
-        in_lo[2] = cur.lo[2] <= Pc[2] + kEps;
-#pragma unroll
-        for (int k = 0; k < 3; k++) in_hi[k] = Pc[k] <= cur.hi[k] + kEps;
-        const float Pa = ax == 0 ? Pc[0] : (ax == 1 ? Pc[1] : Pc[2]);
-        bool split_l = (ts > 0.0f) & (Pa <= s_eps), split_r = (ts > 0.0f) & (s <= Pa + e_ax);
-#pragma unroll
-        for (int k = 0; k < 3; k++) {
-            const bool on = ax == (uint32_t)k;
-            split_l &= in_lo[k] & (in_hi[k] | on);  // left box: hi[ax] is the split plane
-            split_r &= in_hi[k] & (in_lo[k] | on);  // right box: lo[ax] is the split plane
-        }
+        // (logical operators on values that are all computed already: the compiler keeps them as lane masks and combines
+        //  them with scalar instructions; the bitwise forms went through 0/1 integers in vector registers)
+        const bool in_lo0 = cur.lo[0] <= Pc[0], in_lo1 = cur.lo[1] <= Pc[1] + kEps, in_lo2 = cur.lo[2] <= Pc[2] + kEps;
+        const bool in_hi0 = Pc[0] <= cur.hi[0] + kEps, in_hi1 = Pc[1] <= cur.hi[1] + kEps, in_hi2 = Pc[2] <= cur.hi[2] + kEps;
+        const bool on0 = ax == 0u, on1 = ax == 1u, on2 = ax == 2u;
+        const float Pa = on0 ? Pc[0] : (on1 ? Pc[1] : Pc[2]);
+        const bool lo_all = in_lo0 && in_lo1 && in_lo2, hi_all = in_hi0 && in_hi1 && in_hi2;
+        const bool hi_off = (in_hi0 || on0) && (in_hi1 || on1) && (in_hi2 || on2);  // left box: hi[ax] is the split plane
+        const bool lo_off = (in_lo0 || on0) && (in_lo1 || on1) && (in_lo2 || on2);  // right box: lo[ax] is the split plane
+        const bool split_l = (ts > 0.0f) && (Pa <= s_eps) && lo_all && hi_off;
+        const bool split_r = (ts > 0.0f) && (s <= Pa + e_ax) && hi_all && lo_off;
         const float ts_l = split_l ? ts : inf, ts_r = split_r ? ts : inf;
 #pragma unroll
         for (int k = 0; k < 3; k++) {
@@ -344,17 +341,23 @@ PT_HD bool descend_fast(const DScene &sc, f3 o, f3 d, SlabBox &cur, int &node, K
             l_hi[k] = on ? ts_l : l_hi[k];
             r_lo[k] = on ? ts_r : r_lo[k];
         }
-        const float lt = masked_min(l_lo, l_hi);  // mesh.cuh:266-269
-        const float rt = masked_min(r_lo, r_hi);
-        const bool rf = rt < lt;              // Q7: a miss (-1) sorts first
-        const float small_t = rf ? rt : lt, big_t = rf ? lt : rt;
-        bool go_right = (small_t > 0.0f) ? rf : !rf;                 // mesh.cuh:281
-        const bool both = (small_t > 0.0f) & (big_t > 0.0f);         // mesh.cuh:285: the other child is stacked
-        const bool first_dead = go_right ? cull_r : cull_l, other_dead = go_right ? cull_l : cull_r;
+        // Box::intersect of the two children (mesh.cuh:266-269): the minimum of each masked slab, a miss (-1) when nothing is
+        // valid.  Every valid entry is a finite t > 0, so "hit" is "minimum < inf" and the reference's rules -- rt < lt with
+        // a miss sorting first (Q7), enter the nearer hit child (mesh.cuh:281), stack the other when both are hit
+        // (mesh.cuh:285) -- are logic on three compares (kept as lane masks: scalar instructions, not vector selects):
+        //   rf = rt < lt            = l_hit && (!r_hit || rmin < lmin)
+        //   go_right = small_t > 0 ? rf : !rf   = both ? rmin < lmin : !l_hit
+        const float lmin = fmin_raw(fmin3_raw(l_lo[0], l_hi[0], l_lo[1]), fmin3_raw(l_hi[1], l_lo[2], l_hi[2]));
+        const float rmin = fmin_raw(fmin3_raw(r_lo[0], r_hi[0], r_lo[1]), fmin3_raw(r_hi[1], r_lo[2], r_hi[2]));
+        const bool l_hit = lmin < inf, r_hit = rmin < inf, r_nearer = rmin < lmin;
+        const bool both = l_hit && r_hit;
+        bool go_right = (both && r_nearer) || !l_hit;
+        const bool first_dead = (go_right && cull_r) || (!go_right && cull_l);
+        const bool other_dead = (go_right && cull_l) || (!go_right && cull_r);
         if (first_dead) {
-            if (!both | other_dead) return true;  // nothing to find in the child the reference enters, nothing stacked
-            go_right = !go_right;                 // the fruitless visit is skipped: continue with the stacked child
-        } else if (both & !other_dead) {
+            if (!both || other_dead) return true;  // nothing to find in the child the reference enters, nothing stacked
+            go_right = !go_right;                  // the fruitless visit is skipped: continue with the stacked child
+        } else if (both && !other_dead) {
             if (sp < kStackDepth) stk.push(sp, go_right ? left : right);
             sp++;
         }
