@@ -17,11 +17,26 @@ constexpr uint32_t kRngKey1 = 0x6d697074u;  // 'mipt'
 
 PT_HD uint32_t mulhi32(uint32_t a, uint32_t b) { return (uint32_t)(((uint64_t)a * (uint64_t)b) >> 32); }
 
+// 32 x 32 -> 64-bit product, both halves from ONE v_mad_u64_u32 on the device (the compiler splits the product into
+// v_mul_hi_u32 + v_mul_lo_u32: 40 multiplies per Philox block instead of 20; scripts/micro/mulbench.hip)
+PT_HD void mul_wide(uint32_t a, uint32_t b, uint32_t &hi, uint32_t &lo) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    uint64_t r, carry;
+    asm("v_mad_u64_u32 %0, %1, %2, %3, 0" : "=v"(r), "=s"(carry) : "v"(a), "v"(b));
+    hi = (uint32_t)(r >> 32);
+    lo = (uint32_t)r;
+#else
+    const uint64_t r = (uint64_t)a * (uint64_t)b;
+    hi = (uint32_t)(r >> 32);
+    lo = (uint32_t)r;
+#endif
+}
 PT_HD void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t out[4]) {
 #pragma unroll
     for (int r = 0; r < 10; r++) {
-        const uint32_t h0 = mulhi32(0xD2511F53u, c0), l0 = 0xD2511F53u * c0;
-        const uint32_t h1 = mulhi32(0xCD9E8D57u, c2), l1 = 0xCD9E8D57u * c2;
+        uint32_t h0, l0, h1, l1;
+        mul_wide(0xD2511F53u, c0, h0, l0);
+        mul_wide(0xCD9E8D57u, c2, h1, l1);
         const uint32_t n0 = h1 ^ c1 ^ k0, n2 = h0 ^ c3 ^ k1;
         c0 = n0; c1 = l1; c2 = n2; c3 = l0;
         k0 += 0x9E3779B9u;
