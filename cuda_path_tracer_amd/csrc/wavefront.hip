@@ -20,8 +20,8 @@
 //   accumulate                image[id] += trace/nSamples, in sample order               kernel.cu:339-343
 //
 // Queues between stages are built with ballot + mbcnt prefix ranks, an LDS scan over the block's waves and ONE atomic
-// per block and queue; ray counts stay on the device (every extend reads its count from memory) -- the only host round
-// trip inside a pass is the queue length a sort needs.
+// per block and queue; ray counts stay on the device (every extend reads its count from memory) and a pass makes no host
+// round trip: the sorts are sized by the previous render's queue lengths (sort_queue, k_sort_pad / k_sort_tail).
 // Every path's contributions are summed in the reference's order, and the order of a queue changes no result, so the
 // images are bit-identical to the CPU oracle's.
 #include "wavefront.h"
@@ -700,6 +700,19 @@ __global__ __launch_bounds__(kBlock) void k_accumulate(PassParams pp, WfBuffers 
     }
 }
 
+// The radix sort takes its length from the host.  Instead of reading the queue length back (a drain of the stream per
+// sorted queue), a render sorts `n_est` = the previous render's length + 2 % entries: k_sort_pad gives the entries between
+// the true length n (on the device) and n_est the largest key, so the stable sort leaves them behind the real ones, and
+// should the queue have grown beyond n_est, k_sort_tail hands its tail over unsorted.  The order of a queue changes no result.
+__global__ __launch_bounds__(256) void k_sort_pad(uint32_t *keys, const int *count, int n_est, uint32_t sentinel) {
+    const int n = *count;
+    for (int i = n + (int)(blockIdx.x * 256 + threadIdx.x); i < n_est; i += (int)(gridDim.x * 256)) keys[i] = sentinel;
+}
+__global__ __launch_bounds__(256) void k_sort_tail(const int *queue_in, int *sorted, const int *count, int n_est) {
+    const int n = *count;
+    for (int i = n_est + (int)(blockIdx.x * 256 + threadIdx.x); i < n; i += (int)(gridDim.x * 256)) sorted[i] = queue_in[i];
+}
+
 __global__ void k_tally(WfBuffers b, int Dc, int Dl) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     unsigned long long cam = 0, sh = 0, li = 0, ext = 0;
@@ -784,7 +797,7 @@ int wavefront_render(const HostScene &hs, DeviceCtx &dc, const mipt_render_confi
         sizes[25] = sizes[26] = sizes[27] = sizes[28] = sizes[29] = P * 4;  // path_rng, q_cam0, q_light[2], q_ext_light
     }
     // direction binning of the shadow rays (simple integrator, persistent kernel): keys in / out, sorted queue, scratch
-    // (not worth its ~1 ms + host round trip per queue when the trees are a few nodes deep: default scene, 36 triangles)
+    // (not worth its ~1 ms per queue when the trees are a few nodes deep: default scene, 36 triangles)
     const bool sort_shadow = !dc.extend_simple && dc.shadow_sort_from >= 0 && dc.shadow_sort_from < Dc && hs.total_tris >= 4096;
     const bool sort_light = sort_shadow && Dl > 0;  // first light rays: binned by (light, direction)
     size_t sort_temp_bytes = 0;
@@ -826,9 +839,31 @@ int wavefront_render(const HostScene &hs, DeviceCtx &dc, const mipt_render_confi
     hipEvent_t ev_begin = dc.events.next(), ev_end = dc.events.next();
     WF_TRY(hipEventRecord(ev_begin, sm));
 
-    // Stable radix sort of a ray queue by its keys into wf[32]; `queue` then points at the sorted copy.  The sort needs
-    // the queue length on the host: the one kind of host round trip inside a pass (4 bytes, ~20 us).
-    auto sort_queue = [&](const uint32_t *keys, const int *queue_in, int count_slot, unsigned key_bits, const int *&queue) {
+    PassParams pp;
+    pp.n_slots = S;
+    const long long sig = ((long long)npix << 24) ^ ((long long)S << 12) ^ ((long long)Dc << 6) ^ (long long)Dl;
+    if (dc.sort_sig != sig || getenv("MIPT_SORT_SYNC")) {
+        for (double &v : dc.sort_len) v = 0.0;
+        dc.sort_sig = sig;
+    }
+    // Stable radix sort of a ray queue by its keys into wf[32]; `queue` then points at the sorted copy.  Sized by the
+    // previous render's queue length when there is one (see k_sort_pad), else by the length read back from the device.
+    auto sort_queue = [&](const uint32_t *keys, const int *queue_in, int count_slot, unsigned key_bits, const int *&queue, int len_slot) {
+        if (dc.sort_len[len_slot] > 0.0) {
+            const double scaled = dc.sort_len[len_slot] * (double)pp.n_slots / (double)S;
+            const int n_est = (int)std::min<double>((double)(P * K), scaled * 1.02 + 4096.0);
+            const int *count = &b.counts[kCntPad * count_slot];
+            const int fix_grid = std::max(1, std::min(dc.num_cus * 8, n_est / 16 / 256 + 1));
+            hipLaunchKernelGGL(k_sort_pad, dim3(fix_grid), dim3(256), 0, sm, const_cast<uint32_t *>(keys), count, n_est,
+                               key_bits >= 32 ? 0xffffffffu : (1u << key_bits) - 1u);
+            size_t tb = sort_temp_bytes;
+            hipError_t e = rocprim::radix_sort_pairs(dc.wf[33].p, tb, keys, dc.wf[31].as<uint32_t>(), queue_in, dc.wf[32].as<int>(),
+                                                     (size_t)n_est, 0, key_bits, sm);
+            if (e != hipSuccess) return e;
+            hipLaunchKernelGGL(k_sort_tail, dim3(fix_grid), dim3(256), 0, sm, queue_in, dc.wf[32].as<int>(), count, n_est);
+            queue = dc.wf[32].as<int>();
+            return hipSuccess;
+        }
         int n_q = 0;
         hipError_t e = hipMemcpyAsync(&n_q, &b.counts[kCntPad * count_slot], sizeof(int), hipMemcpyDeviceToHost, sm);
         if (e == hipSuccess) e = hipStreamSynchronize(sm);
@@ -851,7 +886,6 @@ int wavefront_render(const HostScene &hs, DeviceCtx &dc, const mipt_render_confi
     };
     const int path_grid = (int)std::min<size_t>((P + kBlock - 1) / kBlock, (size_t)dc.num_cus * 16);
 
-    PassParams pp;
     pp.W = cfg.width; pp.H = cfg.height; pp.npix = npix; pp.spp = cfg.spp; pp.sample_stride = stride;
     pp.Dc = Dc; pp.Dl = Dl; pp.K = K; pp.use_env = cfg.use_envmap ? 1 : 0; pp.seed = cfg.seed;
     pp.tiles_x = (cfg.width % 8 == 0 && cfg.height % 8 == 0) ? cfg.width / 8 : 0;
@@ -872,7 +906,7 @@ int wavefront_render(const HostScene &hs, DeviceCtx &dc, const mipt_render_confi
                 if (sort_light && i == 0) {
                     unsigned light_bits = 0;
                     while ((1 << light_bits) < std::min<int>((int)hs.lights.size(), 256)) light_bits++;
-                    WF_TRY(sort_queue(b.q_light_key, b.q_ext_light, kCntExtLight + 0, kShadowKeyBits + light_bits, light_queue));
+                    WF_TRY(sort_queue(b.q_light_key, b.q_ext_light, kCntExtLight + 0, kShadowKeyBits + light_bits, light_queue, 16));
                 }
                 extend(b.l_o, b.l_d, light_queue, &b.counts[kCntPad * (kCntExtLight + i)], b.l_hit, np, light_queue != b.q_ext_light);
                 hipLaunchKernelGGL(k_light_shade, dim3(path_grid), dim3(kBlock), 0, sm, dc.view, pp, b, i);
@@ -884,7 +918,7 @@ int wavefront_render(const HostScene &hs, DeviceCtx &dc, const mipt_render_confi
             hipLaunchKernelGGL(k_shade, dim3(path_grid), dim3(kBlock), 0, sm, dc.view, pp, b, i);
             const int *shadow_queue = b.q_shadow;
             if (sort_shadow && i >= dc.shadow_sort_from)
-                WF_TRY(sort_queue(b.q_shadow_key, b.q_shadow, kCntShadow + i, kShadowKeyBits, shadow_queue));
+                WF_TRY(sort_queue(b.q_shadow_key, b.q_shadow, kCntShadow + i, kShadowKeyBits, shadow_queue, i));
             const bool binned = shadow_queue != b.q_shadow;
             if (K == 1 && !binned) shadow_queue = nullptr;  // K == 1: the records sit at their queue rank, the unsorted queue is the identity
             extend(pp.common_origins ? nullptr : b.sh_o, b.sh_d, shadow_queue, &b.counts[kCntPad * (kCntShadow + i)], b.sh_hit, np * K,
@@ -904,6 +938,13 @@ int wavefront_render(const HostScene &hs, DeviceCtx &dc, const mipt_render_confi
 #ifdef MIPT_PHASE_STATS
     if (!count_mode) dump_phase_stats(dc, "render");
 #endif
+    if (sort_shadow) {  // the sorted queues' lengths of the last pass, scaled to a full pass: the next render's sort sizes
+        std::vector<int> cnt((size_t)kCntTotal * kCntPad);
+        WF_TRY(hipMemcpy(cnt.data(), b.counts, cnt.size() * sizeof(int), hipMemcpyDeviceToHost));
+        const double full = (double)S / (double)pp.n_slots;
+        for (int i = 0; i < Dc; i++) dc.sort_len[i] = std::max(1.0, full * (double)cnt[(size_t)kCntPad * (kCntShadow + i)]);
+        if (sort_light) dc.sort_len[16] = std::max(1.0, full * (double)cnt[(size_t)kCntPad * (kCntExtLight + 0)]);
+    }
     if (getenv("MIPT_TIMING")) {  // queue lengths of the last pass and the duration of every extend launch, in launch order
         std::vector<int> cnt((size_t)kCntTotal * kCntPad);
         WF_TRY(hipMemcpy(cnt.data(), b.counts, cnt.size() * sizeof(int), hipMemcpyDeviceToHost));

@@ -225,6 +225,32 @@ def test_ray_binning_changes_no_result(monkeypatch):
             assert sa[k] == sb[k], k
 
 
+def test_sorts_sized_by_the_previous_render(monkeypatch):
+    """The radix sorts of the ray queues take their length from the previous render of the same configuration (+2 %), not from
+    a read-back: entries past the true length get the largest key (k_sort_pad), a queue that outgrew the estimate hands
+    its tail over unsorted (k_sort_tail).  Moving the camera between renders makes the queues shrink and grow by far more
+    than the margin; every image equals the one a fresh scene renders (its first render reads the lengths back)."""
+    desc = G.scene_icosphere_room(5)
+    near = ((0.0, -1.0, 1.5), (0.0, -1.0, -2.0), (0.0, 1.0, 0.0), desc.camera[3])   # the sphere fills the frame
+    away = ((-3.5, -4.0, -3.5), (-5.0, -5.0, -5.0), (0.0, 1.0, 0.0), desc.camera[3])  # a floor corner on the light's side, sphere behind
+    s = desc.apply(Scene())
+    s.commit(devices=(0,))
+    for cfg in (make_config(512, 384, spp=4, cam_depth=5, light_depth=0), make_config(320, 240, spp=3, cam_depth=3, light_depth=3)):
+        extended = []
+        for cam in (near, away, near, desc.camera, away):
+            s.set_camera(*cam)
+            img, st = s.render(cfg)
+            fresh = desc.apply(Scene())
+            fresh.set_camera(*cam)
+            fresh.commit(devices=(0,))
+            ref, st_ref = fresh.render(cfg)
+            fresh.close()
+            assert np.array_equal(img.view(np.uint32), ref.view(np.uint32)), cam
+            assert st["rays_extended"] == st_ref["rays_extended"] and st["rays_total"] == st_ref["rays_total"]
+            extended.append(st["rays_extended"])
+        assert max(extended) > 1.2 * min(extended), extended  # the estimates were off by more than their margin, both ways
+
+
 def test_bench_workload_invariants_at_full_resolution(monkeypatch):
     """C2 as bench.py runs it (1920x1080, icosphere L6, simple depth 6), too large for the oracle: size-independent
     properties instead.  The image does not depend on how the samples are split into wavefront passes, on ray binning,
