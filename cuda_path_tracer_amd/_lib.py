@@ -63,6 +63,7 @@ SIGNATURES = {
     "mipt_trace_closest": (C.c_int, [_VP, _VP, _VP, C.c_int64, _VP, _VP, C.POINTER(Stats), C.c_int]),
     "mipt_trace_closest_device": (C.c_int, [_VP, C.c_int, _VP, _VP, C.c_int64, _VP, _VP, C.POINTER(Stats), C.c_int]),
     "mipt_trace_closest_device_noalloc": (C.c_int, [_VP, C.c_int, _VP, _VP, C.c_int64, _VP, _VP]),
+    "mipt_queue_bin_device": (C.c_int, [_VP, C.c_int, _VP, _VP, _VP, C.c_int64, C.c_int, _VP]),
     "mipt_env_lookup": (C.c_int, [_VP, _VP, C.c_int64, _VP]),
     "mipt_scene_gpu_built_meshes": (C.c_int, [_VP]),
     "mipt_hdr_load_rgbe": (C.c_int, [C.c_char_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), _VP]),

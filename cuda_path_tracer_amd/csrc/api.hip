@@ -16,6 +16,7 @@
 
 #include "device_ctx.h"
 #include "kernels_extend.h"
+#include "queue_sort.h"
 #include "scene_host.h"
 #include "wavefront.h"
 
@@ -517,13 +518,19 @@ int mipt_render(mipt_scene *s, const mipt_render_config *cfg, float *out, mipt_s
             const ncclResult_t r = g_rccl.comm_init_all(s->comms.data(), G, ids.data());
             if (r != ncclSuccess) { s->comms.clear(); return fail(-6, std::string("ncclCommInitAll: ") + g_rccl.error_string(r)); }
         }
+        // (a group that was started is always ended, whatever fails inside it: an open group would swallow every later
+        //  collective of the process)
         ncclResult_t r = g_rccl.group_start();
-        for (int g = 0; g < G && r == ncclSuccess; g++) {
+        if (r != ncclSuccess) return fail(-6, std::string("ncclGroupStart: ") + g_rccl.error_string(r));
+        hipError_t he = hipSuccess;
+        for (int g = 0; g < G && r == ncclSuccess && he == hipSuccess; g++) {
             DeviceCtx &dc = s->devs[(size_t)g];
-            HIP_TRY(hipSetDevice(dc.device));
-            r = g_rccl.reduce(dc.accum.p, dc.accum.p, npix * 3, ncclFloat, ncclSum, 0, s->comms[(size_t)g], dc.stream);
+            he = hipSetDevice(dc.device);
+            if (he == hipSuccess)
+                r = g_rccl.reduce(dc.accum.p, dc.accum.p, npix * 3, ncclFloat, ncclSum, 0, s->comms[(size_t)g], dc.stream);
         }
         const ncclResult_t r2 = g_rccl.group_end();
+        if (he != hipSuccess) return fail(-2, std::string("hipSetDevice before ncclReduce: ") + hipGetErrorString(he));
         if (r == ncclSuccess) r = r2;
         if (r != ncclSuccess) return fail(-6, std::string("ncclReduce: ") + g_rccl.error_string(r));
         for (int g = G - 1; g >= 0; g--) {
@@ -579,6 +586,26 @@ int mipt_env_lookup(mipt_scene *s, const float *dirs, int64_t n, float *rgb) {
     int rc = wavefront_env_lookup(dc, dc.io_a.as<float>(), n, dc.io_b.as<float>(), err);
     if (rc != 0) return fail(rc, err);
     HIP_TRY(hipMemcpy(rgb, dc.io_b.p, (size_t)n * 12, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int mipt_queue_bin_device(mipt_scene *s, int slot, const uint32_t *d_keys, const int32_t *d_vals, const int32_t *d_count, int64_t capacity,
+                          int key_bits, int32_t *d_out) {
+    if (!s || !s->committed) return fail(-1, "scene not committed");
+    if (slot < 0 || slot >= (int)s->devs.size()) return fail(-1, "scene is not committed on that device slot");
+    if (!d_keys || !d_vals || !d_count || !d_out) return fail(-1, "null buffer");
+    if (capacity <= 0 || capacity > ((int64_t)1 << 30)) return fail(-1, "queue capacity out of range");
+    if (key_bits < kSortBits1 + kSortBits2 || key_bits > 32) return fail(-1, "key_bits must be 21..32");
+    DeviceCtx &dc = s->devs[slot];
+    HIP_TRY(hipSetDevice(dc.device));
+    HIP_TRY(dc.io_a.reserve((size_t)capacity * 4));
+    HIP_TRY(dc.io_b.reserve((size_t)capacity * 4));
+    HIP_TRY(dc.io_c.reserve((size_t)kSortScratchInts * sizeof(int)));
+    HIP_TRY(wait_for_caller(dc));
+    launch_queue_sort(dc.stream, dc.num_cus, d_keys, d_vals, d_count, (unsigned)key_bits, dc.io_a.as<uint32_t>(), dc.io_b.as<int>(),
+                      dc.io_c.as<int>(), d_out);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(dc.stream));
     return 0;
 }
 

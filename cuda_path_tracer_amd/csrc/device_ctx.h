@@ -101,10 +101,6 @@ struct DeviceCtx {
     DevBuf accum;  // mipt_render: this slot's partial framebuffer (W*H*3 fp32), reduced to slot 0 on the devices
     // wavefront work buffers (see wavefront.hip)
     DevBuf wf[36];
-    // Queue lengths of the previous render's full pass, per sorted queue (shadow queue of camera vertex i; slot 16: the first
-    // light rays): what the next render sizes its sorts by instead of reading each length back (wavefront.hip: sort_queue)
-    double sort_len[17] = {0};
-    long long sort_sig = 0;  // (pixels, samples per pass, depths) the lengths belong to
     EventPool events;
 };
 

@@ -75,8 +75,14 @@ bool HostScene::pack(int n_threads, std::string &err) {
         meshes_built_on_gpu = 0;
         for (size_t m = 0; m < meshes.size(); m++) {
             if (build_device >= 0 && meshes[m].n_tris >= kGpuBuildMinTris) {
-                if (!build_kd_tree_gpu(build_device, meshes[m].pos.data(), meshes[m].n_tris, trees[m], err)) return false;
-                meshes_built_on_gpu++;
+                std::string gpu_err;
+                if (build_kd_tree_gpu(build_device, meshes[m].pos.data(), meshes[m].n_tris, trees[m], gpu_err)) {
+                    meshes_built_on_gpu++;
+                } else {  // e.g. out of device memory: the host builder makes the identical tree, only slower
+                    if (getenv("MIPT_TIMING")) fprintf(stderr, "[mipt] GPU kd build of mesh %zu failed (%s): building it on the host\n", m, gpu_err.c_str());
+                    trees[m] = KdTree();
+                    on_host.push_back(m);
+                }
             } else {
                 on_host.push_back(m);
             }
@@ -466,16 +472,59 @@ bool import_blob(HostScene &s, const uint8_t *blob, size_t size, std::string &er
         err = "not a scene blob of this library version";
         return false;
     }
-    if (h.n_meshes < 0 || h.n_materials < 0 || h.n_lights < 0 || h.n_planes < 0 || h.n_spheres < 0 ||
-        size != sizeof(h) + (size_t)h.n_meshes * sizeof(BlobMesh) + h.arena_bytes || h.layout.total != h.arena_bytes) {
-        err = "scene blob is truncated or inconsistent";
+    if (h.n_meshes < 0 || h.n_materials < 0 || h.n_lights < 0 || h.n_planes < 0 || h.n_spheres < 0 || h.total_tris < 0 ||
+        h.total_nodes < 0 || h.total_refs < 0 || h.env_w < 0 || h.env_h < 0) {
+        err = "scene blob is inconsistent (negative count)";
         return false;
     }
+    {   // total size without wrap-around: header + mesh table + arena
+        const uint64_t rest = (uint64_t)size - sizeof(h);
+        const uint64_t mesh_bytes = (uint64_t)h.n_meshes * sizeof(BlobMesh);
+        if (mesh_bytes > rest || h.arena_bytes != rest - mesh_bytes || h.layout.total != h.arena_bytes) {
+            err = "scene blob is truncated or inconsistent";
+            return false;
+        }
+    }
     const ArenaLayout &L = h.layout;
-    const size_t offs[] = {L.nodes, L.boxes, L.tight, L.tight_pairs, L.refs, L.leaf_planes, L.leaf_spheres, L.leaf_verts, L.tri_pos,
-                           L.tri_nrm, L.meshes, L.mesh_order, L.spheres, L.planes, L.lights, L.materials, L.env};
-    for (size_t o : offs)
-        if (o > h.arena_bytes) { err = "scene blob: section outside the arena"; return false; }
+    // every section must hold what the header says it holds (the tables are read below, the rest by the kernels)
+    auto fits = [&](size_t off, uint64_t count, uint64_t stride) {
+        return off <= h.arena_bytes && count <= (h.arena_bytes - off) / std::max<uint64_t>(stride, 1);
+    };
+    const uint64_t env_texels = (uint64_t)6 * (uint64_t)h.env_w * (uint64_t)h.env_h;
+    const bool sections_ok =
+        fits(L.nodes, (uint64_t)h.total_nodes, sizeof(KdNode)) && fits(L.boxes, (uint64_t)h.total_nodes, 32) &&
+        fits(L.tight, (uint64_t)h.total_nodes, 32) && fits(L.tight_pairs, (uint64_t)h.total_nodes / 2 + 1, 64) &&
+        fits(L.refs, (uint64_t)h.total_refs, 4) && fits(L.leaf_planes, (uint64_t)h.total_refs, 16) &&
+        fits(L.leaf_verts, (uint64_t)h.total_refs, 48) && fits(L.leaf_spheres, (uint64_t)h.total_refs / 2 + 4, sizeof(SpherePair)) &&
+        fits(L.tri_pos, (uint64_t)h.total_tris, 48) && fits(L.tri_nrm, (uint64_t)h.total_tris, 48) &&
+        fits(L.meshes, (uint64_t)h.n_meshes, sizeof(DMesh)) && fits(L.mesh_order, (uint64_t)3 * (uint64_t)h.n_meshes, 4) &&
+        fits(L.spheres, (uint64_t)h.n_spheres, 32) && fits(L.planes, (uint64_t)h.n_planes, 32) &&
+        fits(L.lights, (uint64_t)h.n_lights, 32) && fits(L.materials, (uint64_t)h.n_materials, 32) &&
+        fits(L.env, env_texels, h.env_is_rgbe ? 4 : 12);
+    if (!sections_ok) { err = "scene blob: a section does not fit in the arena"; return false; }
+    if (h.total_nodes >= (int64_t)kIdxMask || h.total_refs >= (int64_t)INT32_MAX || h.total_tris >= (int64_t)(INT32_MAX / 4)) {
+        err = "scene blob: counts beyond the index widths of the layout";
+        return false;
+    }
+    {   // per-mesh ranges: inside the totals, in order, node bases even (sibling pairs)
+        const uint8_t *q = blob + sizeof(h);
+        int64_t tri_at = 0, node_at = 0, ref_at = 0;
+        for (int32_t m = 0; m < h.n_meshes; m++, q += sizeof(BlobMesh)) {
+            BlobMesh bm;
+            memcpy(&bm, q, sizeof(bm));
+            if (bm.n_tris <= 0 || bm.n_nodes <= 0 || bm.n_refs < 0 || bm.tri_base != tri_at || bm.node_base != node_at ||
+                bm.ref_base != ref_at || (bm.node_base & 1) != 0 || bm.n_tris > h.total_tris - tri_at || bm.n_nodes > h.total_nodes - node_at ||
+                bm.n_refs > h.total_refs - ref_at || bm.material < 0 || bm.material >= h.n_materials) {
+                err = "scene blob: mesh table inconsistent with the arena";
+                return false;
+            }
+            tri_at += bm.n_tris; node_at += bm.n_nodes; ref_at += bm.n_refs;
+        }
+        if (tri_at != h.total_tris || node_at != h.total_nodes || ref_at != h.total_refs) {
+            err = "scene blob: mesh table does not add up to the totals";
+            return false;
+        }
+    }
     s = HostScene();
     // the small tables are read back from the arena sections the packer wrote them to
     const uint8_t *p = blob + sizeof(h);

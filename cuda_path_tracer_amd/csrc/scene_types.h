@@ -4,16 +4,25 @@
 // per-leaf 72-byte triangle copies, mesh.cuh:204-220, mesh.cu:35-36) and the ~2 allocations per
 // leaf made through copyToDevice (copyToDevice.h:8-55).  The whole scene lives in ONE device arena:
 //
-//   nodes    uint2[n_nodes]     8-byte kd node.  interior: x = bits(split plane), y = axis<<30 | left child
-//                               (right child = left + 1, pair 16-byte aligned); leaf: x = first ref, y = 3<<30 | count
-//   boxes    float4[2*n_nodes]  (minX,maxX,minY,maxY) (minZ,maxZ,-,-): read for the root and on stack pops only
-//   refs     int32[n_refs]      leaf triangle index lists (global triangle ids, leaf order = input order)
-//   leaf_planes float4[n_refs]   plane record (N, -N.a) of each reference, contiguous per leaf: the leaf loop
-//                               streams these 16-byte records and touches vertices only for survivors
-//   tri_pos  float4[3*n_tris]   vertex positions a,b,c (w unused) -- three 16-byte loads per candidate
-//   tri_nrm  float4[3*n_tris]   vertex normals, fetched once for the winning triangle
-//   meshes / spheres / planes / lights / materials: small tables; wave-uniform reads go through ldk4() below
-//   env      6 cube faces, raw RGBE (4 B/texel) or fp32 RGB
+//   nodes       uint2[n_nodes]      8-byte kd node.  interior: x = bits(split plane), y = axis<<30 | recheck<<29 | left child
+//                                   (right child = left + 1, pair 16-byte aligned); leaf: x = first ref, y = 3<<30 | count.
+//                                   Read for mesh roots and stack pops; the node steps read the copy in tight_pairs
+//   boxes       float4[2*n_nodes]   the node's box (minX,maxX,minY,maxY) (minZ,maxZ,-,-): root and stack pops only
+//   tight       float4[2*n_nodes]   cull box, same layout: leaf = AABB(leaf triangles) within the leaf box, interior = union
+//                                   of the children's; root cull / whole-mesh skip, reference-walk counting kernel
+//   tight_pairs float4[4*(n/2+1)]   THE STEP RECORD, 64 B per sibling pair (left child index >> 1): the two cull boxes grown by
+//                                   their margin, component-interleaved (loL,loR,hiL,hiR) per axis (48 B) + the two children's
+//                                   8-byte nodes (16 B): one half cache line per node step
+//   refs        int32[n_refs]       leaf triangle index lists (global triangle ids, leaf order = input order); read once per
+//                                   leaf scan that found a hit (reference position -> triangle id)
+//   leaf_spheres SpherePair[n_refs/2+4] 32 B per PAIR of references: conservative candidate spheres, streamed by pass 1 of the
+//                                   leaf scan (packed fp32)
+//   leaf_planes float4[n_refs]      plane record (N, -N.a) of each reference, contiguous per leaf: pass 2, marked candidates
+//   leaf_verts  float4[3*n_refs]    the reference's three vertex positions again, in leaf order (no reference -> triangle hop)
+//   tri_pos     float4[3*n_tris]    vertex positions a,b,c (w unused), triangle order: shading (surface_at)
+//   tri_nrm     float4[3*n_tris]    vertex normals, fetched once for the winning triangle
+//   meshes / mesh_order / spheres / planes / lights / materials: small tables; wave-uniform reads go through ldk4() below
+//   env         6 cube faces, raw RGBE (4 B/texel) or fp32 RGB
 #pragma once
 #include <stdint.h>
 #include "pt_math.h"

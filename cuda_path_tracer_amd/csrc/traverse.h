@@ -6,16 +6,19 @@
 // (mesh.cuh:36-90), Plane::intersect (plane.cuh:18-30) and Sphere::intersect (sphere.cuh:19-37),
 // reproduced bit for bit in fp32, including the quirks catalogued in SURVEY.md 8.1 (Q3-Q8).
 //
-// What is different is the machine mapping:
+// What is different is the machine mapping (layout: scene_types.h):
 //  * 8-byte nodes.  A child's box differs from its parent's in ONE plane (Box::half, mesh.cu:5-30),
 //    so the current node's six bounds and the ray parameter of each of its six slab planes are
-//    carried in registers; descending costs one 8-byte node read and ONE division (the split
-//    plane) instead of two 80-byte nodes and twelve divisions.  The values are the same fp32
-//    values the reference computes, because they come from the same expressions.
+//    carried in registers; descending costs ONE division (the split plane) instead of two 80-byte
+//    nodes and twelve divisions, and one 64-byte step record (tight_pairs: both children's cull boxes
+//    and 8-byte nodes).  The values are the same fp32 values the reference computes, because they come
+//    from the same expressions.
 //  * The per-node 32-byte box is re-read only for the root and after a stack pop.
+//  * Subtrees whose cull box (tight / tight_pairs) the ray misses are neither entered nor stacked.
 //  * The traversal stack lives in LDS (one column per lane, bank-conflict free).
-//  * In a leaf, candidates that cannot win (t <= 0, t >= best, point outside the leaf box) are
-//    rejected before the three edge tests; the vertex normals are never touched here.
+//  * In a leaf, pass 1 streams conservative candidate spheres (leaf_spheres, packed fp32); only the
+//    marked candidates get the reference's evaluation from leaf-ordered plane and vertex records
+//    (leaf_planes, leaf_verts); the vertex normals are never touched here.
 #pragma once
 #include "scene_types.h"
 

@@ -12,27 +12,27 @@
 //   extend                    closest hit of the camera rays                             kernel.cu:240
 //   shade(i)                  direct-light + light-vertex connections emitted as batched shadow rays,
 //                             BSDF sampling / roulette, next ray, queue compaction        kernel.cu:244-302
-//   [sort]                    shadow queue of vertex >= 1 (and the first light rays) ordered by direction: they
-//                             share an origin, so binned they are as coherent as primary rays (rocPRIM radix sort)
+//   [bin]                     shadow queue of vertex >= 1 (and the first light rays) ordered by direction: they
+//                             share an origin, so binned they are as coherent as primary rays (queue_sort.h)
 //   extend                    closest hit of the shadow-ray batch (all rays are closest-hit, Q10)
 //   resolve                   visibility compare + in-order accumulation of contributions kernel.cu:249-256,268-279
 //                             (connections answered without the extend kernel are resolved by shade itself)
 //   accumulate                image[id] += trace/nSamples, in sample order               kernel.cu:339-343
 //
 // Queues between stages are built with ballot + mbcnt prefix ranks, an LDS scan over the block's waves and ONE atomic
-// per block and queue; ray counts stay on the device (every extend reads its count from memory) and a pass makes no host
-// round trip: the sorts are sized by the previous render's queue lengths (sort_queue, k_sort_pad / k_sort_tail).
+// per block and queue; ray counts stay on the device (every extend and every binning kernel reads its count from memory)
+// and a pass makes no host round trip.
 // Every path's contributions are summed in the reference's order, and the order of a queue changes no result, so the
 // images are bit-identical to the CPU oracle's.
 #include "wavefront.h"
 
 #include <hip/hip_runtime.h>
-#include <rocprim/device/device_radix_sort.hpp>
 
 #include <algorithm>
 #include <cstring>
 
 #include "kernels_extend.h"
+#include "queue_sort.h"
 #include "shade.h"
 
 namespace mipt {
@@ -700,19 +700,6 @@ __global__ __launch_bounds__(kBlock) void k_accumulate(PassParams pp, WfBuffers 
     }
 }
 
-// The radix sort takes its length from the host.  Instead of reading the queue length back (a drain of the stream per
-// sorted queue), a render sorts `n_est` = the previous render's length + 2 % entries: k_sort_pad gives the entries between
-// the true length n (on the device) and n_est the largest key, so the stable sort leaves them behind the real ones, and
-// should the queue have grown beyond n_est, k_sort_tail hands its tail over unsorted.  The order of a queue changes no result.
-__global__ __launch_bounds__(256) void k_sort_pad(uint32_t *keys, const int *count, int n_est, uint32_t sentinel) {
-    const int n = *count;
-    for (int i = n + (int)(blockIdx.x * 256 + threadIdx.x); i < n_est; i += (int)(gridDim.x * 256)) keys[i] = sentinel;
-}
-__global__ __launch_bounds__(256) void k_sort_tail(const int *queue_in, int *sorted, const int *count, int n_est) {
-    const int n = *count;
-    for (int i = n_est + (int)(blockIdx.x * 256 + threadIdx.x); i < n; i += (int)(gridDim.x * 256)) sorted[i] = queue_in[i];
-}
-
 __global__ void k_tally(WfBuffers b, int Dc, int Dl) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     unsigned long long cam = 0, sh = 0, li = 0, ext = 0;
@@ -800,16 +787,14 @@ int wavefront_render(const HostScene &hs, DeviceCtx &dc, const mipt_render_confi
     // (not worth its ~1 ms per queue when the trees are a few nodes deep: default scene, 36 triangles)
     const bool sort_shadow = !dc.extend_simple && dc.shadow_sort_from >= 0 && dc.shadow_sort_from < Dc && hs.total_tris >= 4096;
     const bool sort_light = sort_shadow && Dl > 0;  // first light rays: binned by (light, direction)
-    size_t sort_temp_bytes = 0;
     if (sort_shadow) {
-        sizes[30] = sizes[31] = sizes[32] = P * K * 4;  // keys in / keys out (scratch) / sorted queue
-        WF_TRY(rocprim::radix_sort_pairs(nullptr, sort_temp_bytes, (uint32_t *)nullptr, (uint32_t *)nullptr, (int *)nullptr,
-                                         (int *)nullptr, P * K, 0, 32, dc.stream));
-        sizes[33] = sort_temp_bytes;
+        // keys in / intermediate keys / binned queue / intermediate values (queue_sort.h), + the small scan scratch
+        sizes[30] = sizes[31] = sizes[32] = sizes[33] = P * K * 4;
+        sizes[35] = (size_t)kSortScratchInts * sizeof(int);
         if (sort_light) sizes[34] = P * 4;
     }
-    static_assert(sizeof(dc.wf) / sizeof(dc.wf[0]) >= 35, "wf buffer table too small");
-    for (int i = 0; i < 35; i++)
+    static_assert(sizeof(dc.wf) / sizeof(dc.wf[0]) >= 36, "wf buffer table too small");
+    for (int i = 0; i < 36; i++)
         if (sizes[i]) WF_TRY(dc.wf[i].reserve(sizes[i]));
     WfBuffers b;
     memset(&b, 0, sizeof(b));
@@ -841,38 +826,12 @@ int wavefront_render(const HostScene &hs, DeviceCtx &dc, const mipt_render_confi
 
     PassParams pp;
     pp.n_slots = S;
-    const long long sig = ((long long)npix << 24) ^ ((long long)S << 12) ^ ((long long)Dc << 6) ^ (long long)Dl;
-    if (dc.sort_sig != sig || getenv("MIPT_SORT_SYNC")) {
-        for (double &v : dc.sort_len) v = 0.0;
-        dc.sort_sig = sig;
-    }
-    // Stable radix sort of a ray queue by its keys into wf[32]; `queue` then points at the sorted copy.  Sized by the
-    // previous render's queue length when there is one (see k_sort_pad), else by the length read back from the device.
-    auto sort_queue = [&](const uint32_t *keys, const int *queue_in, int count_slot, unsigned key_bits, const int *&queue, int len_slot) {
-        if (dc.sort_len[len_slot] > 0.0) {
-            const double scaled = dc.sort_len[len_slot] * (double)pp.n_slots / (double)S;
-            const int n_est = (int)std::min<double>((double)(P * K), scaled * 1.02 + 4096.0);
-            const int *count = &b.counts[kCntPad * count_slot];
-            const int fix_grid = std::max(1, std::min(dc.num_cus * 8, n_est / 16 / 256 + 1));
-            hipLaunchKernelGGL(k_sort_pad, dim3(fix_grid), dim3(256), 0, sm, const_cast<uint32_t *>(keys), count, n_est,
-                               key_bits >= 32 ? 0xffffffffu : (1u << key_bits) - 1u);
-            size_t tb = sort_temp_bytes;
-            hipError_t e = rocprim::radix_sort_pairs(dc.wf[33].p, tb, keys, dc.wf[31].as<uint32_t>(), queue_in, dc.wf[32].as<int>(),
-                                                     (size_t)n_est, 0, key_bits, sm);
-            if (e != hipSuccess) return e;
-            hipLaunchKernelGGL(k_sort_tail, dim3(fix_grid), dim3(256), 0, sm, queue_in, dc.wf[32].as<int>(), count, n_est);
-            queue = dc.wf[32].as<int>();
-            return hipSuccess;
-        }
-        int n_q = 0;
-        hipError_t e = hipMemcpyAsync(&n_q, &b.counts[kCntPad * count_slot], sizeof(int), hipMemcpyDeviceToHost, sm);
-        if (e == hipSuccess) e = hipStreamSynchronize(sm);
-        if (e != hipSuccess || n_q <= 1) return e;
-        size_t tb = sort_temp_bytes;
-        e = rocprim::radix_sort_pairs(dc.wf[33].p, tb, keys, dc.wf[31].as<uint32_t>(), queue_in, dc.wf[32].as<int>(), (size_t)n_q, 0,
-                                      key_bits, sm);
-        if (e == hipSuccess) queue = dc.wf[32].as<int>();
-        return e;
+    // Bin a ray queue by the top bits of its keys into wf[32] (queue_sort.h); `queue` then points at the binned copy.  The
+    // queue's length never leaves the device.
+    auto sort_queue = [&](const uint32_t *keys, const int *queue_in, int count_slot, unsigned key_bits, const int *&queue) {
+        launch_queue_sort(sm, dc.num_cus, keys, queue_in, &b.counts[kCntPad * count_slot], key_bits, dc.wf[31].as<uint32_t>(),
+                          dc.wf[33].as<int>(), dc.wf[35].as<int>(), dc.wf[32].as<int>());
+        queue = dc.wf[32].as<int>();
     };
     int n_launch = 0;
     auto extend = [&](const f4 *ro, const f4 *rd, const int *queue, const int *count, HitRec *hits, size_t n_max, bool coherent_queue,
@@ -906,7 +865,7 @@ int wavefront_render(const HostScene &hs, DeviceCtx &dc, const mipt_render_confi
                 if (sort_light && i == 0) {
                     unsigned light_bits = 0;
                     while ((1 << light_bits) < std::min<int>((int)hs.lights.size(), 256)) light_bits++;
-                    WF_TRY(sort_queue(b.q_light_key, b.q_ext_light, kCntExtLight + 0, kShadowKeyBits + light_bits, light_queue, 16));
+                    sort_queue(b.q_light_key, b.q_ext_light, kCntExtLight + 0, kShadowKeyBits + light_bits, light_queue);
                 }
                 extend(b.l_o, b.l_d, light_queue, &b.counts[kCntPad * (kCntExtLight + i)], b.l_hit, np, light_queue != b.q_ext_light);
                 hipLaunchKernelGGL(k_light_shade, dim3(path_grid), dim3(kBlock), 0, sm, dc.view, pp, b, i);
@@ -918,7 +877,7 @@ int wavefront_render(const HostScene &hs, DeviceCtx &dc, const mipt_render_confi
             hipLaunchKernelGGL(k_shade, dim3(path_grid), dim3(kBlock), 0, sm, dc.view, pp, b, i);
             const int *shadow_queue = b.q_shadow;
             if (sort_shadow && i >= dc.shadow_sort_from)
-                WF_TRY(sort_queue(b.q_shadow_key, b.q_shadow, kCntShadow + i, kShadowKeyBits, shadow_queue, i));
+                sort_queue(b.q_shadow_key, b.q_shadow, kCntShadow + i, kShadowKeyBits, shadow_queue);
             const bool binned = shadow_queue != b.q_shadow;
             if (K == 1 && !binned) shadow_queue = nullptr;  // K == 1: the records sit at their queue rank, the unsorted queue is the identity
             extend(pp.common_origins ? nullptr : b.sh_o, b.sh_d, shadow_queue, &b.counts[kCntPad * (kCntShadow + i)], b.sh_hit, np * K,
@@ -938,13 +897,6 @@ int wavefront_render(const HostScene &hs, DeviceCtx &dc, const mipt_render_confi
 #ifdef MIPT_PHASE_STATS
     if (!count_mode) dump_phase_stats(dc, "render");
 #endif
-    if (sort_shadow) {  // the sorted queues' lengths of the last pass, scaled to a full pass: the next render's sort sizes
-        std::vector<int> cnt((size_t)kCntTotal * kCntPad);
-        WF_TRY(hipMemcpy(cnt.data(), b.counts, cnt.size() * sizeof(int), hipMemcpyDeviceToHost));
-        const double full = (double)S / (double)pp.n_slots;
-        for (int i = 0; i < Dc; i++) dc.sort_len[i] = std::max(1.0, full * (double)cnt[(size_t)kCntPad * (kCntShadow + i)]);
-        if (sort_light) dc.sort_len[16] = std::max(1.0, full * (double)cnt[(size_t)kCntPad * (kCntExtLight + 0)]);
-    }
     if (getenv("MIPT_TIMING")) {  // queue lengths of the last pass and the duration of every extend launch, in launch order
         std::vector<int> cnt((size_t)kCntTotal * kCntPad);
         WF_TRY(hipMemcpy(cnt.data(), b.counts, cnt.size() * sizeof(int), hipMemcpyDeviceToHost));

@@ -48,13 +48,21 @@ def render_distributed(render_into, accum, sample_begin, sample_end, rank, world
 def broadcast_blob(blob, rank, world, device=None):
     """Broadcasts a uint8 numpy array from rank 0 over the default torch.distributed process group (RCCL needs the
     buffer on the GPU: pass this rank's torch device; gloo takes host tensors: device=None).  Returns the array on
-    every rank."""
+    every rank.  Rank 0 may pass an Exception instead of an array (its build failed): the size travels as -1 and EVERY
+    rank raises, instead of the peers waiting in the second broadcast for ever."""
     if world == 1:
+        if isinstance(blob, BaseException):
+            raise blob
         return blob
     import torch
     import torch.distributed as dist
-    size = torch.tensor([blob.size if rank == 0 else 0], dtype=torch.int64, device=device)
+    failed = rank == 0 and isinstance(blob, BaseException)
+    size = torch.tensor([(-1 if failed else blob.size) if rank == 0 else 0], dtype=torch.int64, device=device)
     dist.broadcast(size, src=0)
+    if int(size.item()) < 0:
+        if failed:
+            raise blob
+        raise RuntimeError("rank 0 failed to build the scene; nothing to import on rank %d" % rank)
     if rank == 0:
         buf = torch.from_numpy(np.ascontiguousarray(blob, dtype=np.uint8))
         buf = buf.to(device) if device is not None else buf.clone()
@@ -68,12 +76,17 @@ def share_scene(build, make_empty, rank, world, device=None):
     """Build once, ship everywhere.  `build()` -> a scene that has been described and packed on the host
     (`commit(devices=())`), called on rank 0 only; `make_empty()` -> an empty scene of the same class.  Returns this
     rank's scene, packed but not yet uploaded: the caller commits it on its own device (which for an imported scene
-    only uploads)."""
+    only uploads).  If `build()` raises on rank 0, every rank raises (see broadcast_blob)."""
     if world == 1:
         return build()
     if rank == 0:
-        scene = build()
-        broadcast_blob(scene.export_blob(), rank, world, device)
+        try:
+            scene = build()
+            blob = scene.export_blob()
+        except Exception as e:  # tell the peers before re-raising
+            broadcast_blob(e, rank, world, device)
+            raise
+        broadcast_blob(blob, rank, world, device)
         return scene
     scene = make_empty()
     scene.import_blob(broadcast_blob(None, rank, world, device))

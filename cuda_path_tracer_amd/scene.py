@@ -169,6 +169,12 @@ class Scene:
         check(self._lib.mipt_trace_closest_device_noalloc(self._h, int(dev_slot), C.c_void_p(int(o_ptr)), C.c_void_p(int(d_ptr)),
                                                           int(n), C.c_void_p(int(prim_ptr)), C.c_void_p(int(t_ptr))))
 
+    def queue_bin_device(self, keys_ptr, vals_ptr, count_ptr, capacity, key_bits, out_ptr, dev_slot=0):
+        """The renderer's queue-binning stage (csrc/queue_sort.h) on caller-provided device buffers; the length is the
+        int32 at count_ptr (device memory)."""
+        check(self._lib.mipt_queue_bin_device(self._h, int(dev_slot), C.c_void_p(int(keys_ptr)), C.c_void_p(int(vals_ptr)),
+                                              C.c_void_p(int(count_ptr)), int(capacity), int(key_bits), C.c_void_p(int(out_ptr))))
+
     def env_lookup(self, dirs):
         dirs = np.ascontiguousarray(dirs, dtype=np.float32).reshape(-1, 3)
         rgb = np.empty_like(dirs)

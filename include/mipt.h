@@ -100,7 +100,9 @@ int  mipt_scene_commit(mipt_scene *, const int *device_ids, int n_devices);
 
 /* ---- rendering: replaces render<<<>>> + cudaMemcpy D2H (kernel.cu:310-346,397,416) ---- */
 /* out_rgb_f32: host W*H*3, row r <-> camera Y=r (camera.cuh:18), value = sum_s trace_s / spp. With
- * several committed devices the sample set is partitioned s mod G and summed on the host. */
+ * several committed devices the sample set is partitioned s mod G, every device renders its share into a
+ * device framebuffer and ONE RCCL reduce (sum, fp32, W*H*3) over xGMI brings them to slot 0 before the single
+ * device-to-host copy that replaces kernel.cu:416 (no host-side sum; librccl missing = error). */
 int  mipt_render(mipt_scene *, const mipt_render_config *, float *out_rgb_f32, mipt_stats *out);
 /* Same on committed device slot `dev_slot`, ADDING into a caller-provided DEVICE buffer (W*H*3 fp32),
  * e.g. the tensor a caller then all-reduces over RCCL. Synchronises the scene stream before returning. */
@@ -126,6 +128,13 @@ int  mipt_trace_closest_device(mipt_scene *, int dev_slot, const float *d_ray_o,
  * No statistics.  Every call on one GPU shares that array: calls that overlap on one GPU race -- serialise them. */
 int  mipt_trace_closest_device_noalloc(mipt_scene *, int dev_slot, const float *d_ray_o, const float *d_ray_d, int64_t n,
                                        int32_t *d_prim_id, float *d_t);
+/* No counterpart in the reference (its megakernel has no queues, kernel.cu:310-346): the queue-binning stage the renderer runs
+ * in front of the closest-hit kernel (csrc/queue_sort.h), exposed for tests and tools.  Bins d_vals[0, *d_count) by the top 21
+ * of the key_bits (21..32) significant bits of d_keys[] into d_out[0, *d_count): a permutation of the input in which the top
+ * 10 key bits never decrease and every run of equal top-10 bits consists of at most ceil(len / 16384) runs ordered by the next
+ * 11 bits.  The length is read from DEVICE memory (*d_count <= capacity); all four buffers live on device slot `dev_slot`. */
+int  mipt_queue_bin_device(mipt_scene *, int dev_slot, const uint32_t *d_keys, const int32_t *d_vals, const int32_t *d_count,
+                           int64_t capacity, int key_bits, int32_t *d_out);
 /* EnvMap::getPixelColor envMap.cuh:50-89 evaluated on the device for n directions (host buffers). */
 int  mipt_env_lookup(mipt_scene *, const float *dirs, int64_t n, float *rgb);
 

@@ -87,6 +87,37 @@ def test_two_rank_sample_partition_allreduce(tmp_path):
     assert full.mean() > 0.01
 
 
+def _worker_build_fails(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from cuda_path_tracer_amd.parallel import share_scene
+    from cuda_path_tracer_amd.scene import Scene
+
+    def build():
+        raise ValueError("no such asset")
+
+    try:
+        share_scene(build, Scene, rank, world, device=None)
+        what = "returned"
+    except ValueError as e:
+        what = "ValueError: %s" % e
+    except RuntimeError as e:
+        what = "RuntimeError: %s" % e
+    open(os.path.join(out_dir, "fail%d.txt" % rank), "w").write(what)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_failed_build_on_rank0_raises_on_every_rank(tmp_path):
+    """share_scene: when build() raises on rank 0 the peers must not wait in the broadcast for ever -- the size travels
+    as -1 and every rank raises."""
+    mp.spawn(_worker_build_fails, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    assert open(tmp_path / "fail0.txt").read() == "ValueError: no such asset"
+    assert open(tmp_path / "fail1.txt").read().startswith("RuntimeError: rank 0 failed to build the scene")
+
+
 def test_rank_samples_cover_range_exactly_once():
     from cuda_path_tracer_amd.parallel import count_samples, rank_samples
     for world in (1, 2, 3, 4, 8):

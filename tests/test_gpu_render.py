@@ -170,7 +170,8 @@ def test_render_argument_errors():
 
 
 def test_two_device_slots_in_one_process():
-    # mipt_render over several committed device slots (one host thread and stream per slot, samples s mod G, host sum).
+    # mipt_render over several committed device slots (one host thread and stream per slot, samples s mod G, partial
+    # framebuffers combined on the devices: one RCCL reduce for distinct devices, a kernel for slots that share one).
     # With one GPU in the box both slots live on device 0, which still runs the whole multi-slot code path.
     desc = G.scene_icosphere_room(3)
     two = desc.apply(Scene())
@@ -203,7 +204,7 @@ def test_coincident_meshes_render_bit_exact():
 
 
 def test_ray_binning_changes_no_result(monkeypatch):
-    """Shadow / first light rays are radix-sorted by direction before the closest-hit kernel (scenes >= 4096 triangles;
+    """Shadow / first light rays are binned by direction before the closest-hit kernel (scenes >= 4096 triangles;
     MIPT_SHADOW_SORT=-1, read at commit, switches it off): same images bit for bit, same ray counts, equal to the oracle."""
     desc = G.scene_icosphere_room(5)  # 20,480 triangles
     binned = desc.apply(Scene())
@@ -225,11 +226,10 @@ def test_ray_binning_changes_no_result(monkeypatch):
             assert sa[k] == sb[k], k
 
 
-def test_sorts_sized_by_the_previous_render(monkeypatch):
-    """The radix sorts of the ray queues take their length from the previous render of the same configuration (+2 %), not from
-    a read-back: entries past the true length get the largest key (k_sort_pad), a queue that outgrew the estimate hands
-    its tail over unsorted (k_sort_tail).  Moving the camera between renders makes the queues shrink and grow by far more
-    than the margin; every image equals the one a fresh scene renders (its first render reads the lengths back)."""
+def test_binned_queues_follow_the_scene_from_render_to_render():
+    """The binning stage takes every queue length from device memory (rounds 1-2 sized a library sort by the previous
+    render's lengths).  Moving the camera between renders of one scene object makes the queues shrink and grow by large
+    factors; every image equals the one a fresh scene renders."""
     desc = G.scene_icosphere_room(5)
     near = ((0.0, -1.0, 1.5), (0.0, -1.0, -2.0), (0.0, 1.0, 0.0), desc.camera[3])   # the sphere fills the frame
     away = ((-3.5, -4.0, -3.5), (-5.0, -5.0, -5.0), (0.0, 1.0, 0.0), desc.camera[3])  # a floor corner on the light's side, sphere behind
@@ -248,7 +248,25 @@ def test_sorts_sized_by_the_previous_render(monkeypatch):
             assert np.array_equal(img.view(np.uint32), ref.view(np.uint32)), cam
             assert st["rays_extended"] == st_ref["rays_extended"] and st["rays_total"] == st_ref["rays_total"]
             extended.append(st["rays_extended"])
-        assert max(extended) > 1.2 * min(extended), extended  # the estimates were off by more than their margin, both ways
+        assert max(extended) > 1.2 * min(extended), extended
+
+
+def test_full_light_queue_binned_at_a_small_pass_size():
+    """Round 2's library sort over-ran the first-light-ray key buffer when that queue was (nearly) full and the pass small
+    (advisor finding): a light INSIDE a mesh of >= 4096 triangles queues every light ray, 64x64 at 1 spp is a 4096-path
+    pass.  Rendered twice in a row (the second render is the one that over-ran) and held against the oracle."""
+    desc = G.scene_icosphere_room(5)
+    kind, pos, nrm, mat = desc.meshes[0]
+    centre = np.asarray(desc.lights[0][0], np.float32)
+    big, big_n = G.icosphere(5, 3.0, tuple(float(c) for c in centre))  # 20,480 triangles around lights[0]
+    desc.meshes.append(("arrays", big, big_n, mat))
+    s, o = _pair(desc)
+    for cfg in (make_config(64, 64, spp=1, cam_depth=3, light_depth=2), make_config(64, 64, spp=2, cam_depth=2, light_depth=3)):
+        ref, _ = o.render(cfg)
+        for _ in range(2):
+            img, st = s.render(cfg)
+            assert np.array_equal(img.view(np.uint32), ref.view(np.uint32))
+            assert st["rays_light"] >= 64 * 64 * cfg.spp
 
 
 def test_bench_workload_invariants_at_full_resolution(monkeypatch):

@@ -137,6 +137,22 @@ def test_export_import_round_trip(cube_obj):
     bad[0] ^= 0xFF
     with pytest.raises(_lib.MiptError, match="blob"):
         Scene().import_blob(bad)
+    # a corrupt header must be refused before anything is read through it (offsets: BlobHeader / BlobMesh in scene.cpp):
+    # table counts that do not fit their sections, mesh ranges that leave the arena, totals that do not add up
+    def patched(offset, value, dtype):
+        out = blob.copy()
+        out[offset:offset + np.dtype(dtype).itemsize] = np.array([value], dtype).view(np.uint8)
+        return out
+    for off, val, dt in ((200, 1 << 27, np.int32),      # n_planes
+                         (192, 1 << 30, np.int32),      # n_materials
+                         (176, 1 << 28, np.int64),      # total_nodes
+                         (184, (1 << 31) - 2, np.int64),  # total_refs
+                         (24 + 8 * 13, blob.size, np.uint64),  # layout.planes beyond the arena
+                         (288 + 0, 1 << 40, np.int64),   # mesh 0: n_tris
+                         (288 + 16, 3, np.int64),        # mesh 0: node_base
+                         (288 + 80 + 32, 1 << 33, np.int64)):  # mesh 1: n_nodes
+        with pytest.raises(_lib.MiptError, match="blob"):
+            Scene().import_blob(patched(off, val, dt))
 
 
 def test_error_behaviour_without_device():

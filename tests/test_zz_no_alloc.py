@@ -35,8 +35,13 @@ def test_noalloc_entry_point_matches_the_allocating_one():
         got_p, got_t = ref_p.clone(), ref_t.clone()
         torch.cuda.synchronize()
         s.trace_closest_device(d_o.data_ptr(), d_d.data_ptr(), n, ref_p.data_ptr(), ref_t.data_ptr())
+        # "allocates nothing": free device memory as the DRIVER sees it (hipMemGetInfo: a hipMalloc / hipFree inside libmipt
+        # would move it; torch's own counter only sees torch's caching allocator) is the same before and after the call
         before = torch.cuda.memory_allocated()
+        free_before, _ = torch.cuda.mem_get_info()
         _lib.check(_noalloc(lib, s, d_o, d_d, n, got_p, got_t))
+        free_after, _ = torch.cuda.mem_get_info()
+        assert free_after == free_before, (free_before, free_after)
         assert torch.cuda.memory_allocated() == before
         assert torch.equal(got_p, ref_p)
         assert torch.equal(got_t.view(torch.int32), ref_t.view(torch.int32))
