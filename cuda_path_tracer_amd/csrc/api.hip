@@ -595,7 +595,7 @@ int mipt_queue_bin_device(mipt_scene *s, int slot, const uint32_t *d_keys, const
     if (slot < 0 || slot >= (int)s->devs.size()) return fail(-1, "scene is not committed on that device slot");
     if (!d_keys || !d_vals || !d_count || !d_out) return fail(-1, "null buffer");
     if (capacity <= 0 || capacity > ((int64_t)1 << 30)) return fail(-1, "queue capacity out of range");
-    if (key_bits < kSortBits1 + kSortBits2 || key_bits > 32) return fail(-1, "key_bits must be 21..32");
+    if (key_bits < kSortFineBits || key_bits > 32) return fail(-1, "key_bits must be 14..32");
     DeviceCtx &dc = s->devs[slot];
     HIP_TRY(hipSetDevice(dc.device));
     HIP_TRY(dc.io_a.reserve((size_t)capacity * 4));

@@ -129,10 +129,12 @@ int  mipt_trace_closest_device(mipt_scene *, int dev_slot, const float *d_ray_o,
 int  mipt_trace_closest_device_noalloc(mipt_scene *, int dev_slot, const float *d_ray_o, const float *d_ray_d, int64_t n,
                                        int32_t *d_prim_id, float *d_t);
 /* No counterpart in the reference (its megakernel has no queues, kernel.cu:310-346): the queue-binning stage the renderer runs
- * in front of the closest-hit kernel (csrc/queue_sort.h), exposed for tests and tools.  Bins d_vals[0, *d_count) by the top 21
- * of the key_bits (21..32) significant bits of d_keys[] into d_out[0, *d_count): a permutation of the input in which the top
- * 10 key bits never decrease and every run of equal top-10 bits consists of at most ceil(len / 16384) runs ordered by the next
- * 11 bits.  The length is read from DEVICE memory (*d_count <= capacity); all four buffers live on device slot `dev_slot`. */
+ * in front of the closest-hit kernel (csrc/queue_sort.h), exposed for tests and tools.  Orders d_vals[0, *d_count) by the
+ * key_bits (14..32) significant bits of d_keys[] into d_out[0, *d_count): a permutation of the input in which the top 14 key
+ * bits decrease at most *d_count / 262144 times (slices of a bucket that one crowded key range made huge) and neighbouring
+ * keys are in order up to a tolerance that shrinks where the keys are dense (a sample sort with splitters from the queue's own
+ * histogram; entries with equal keys come out in no particular order).  The length is read from DEVICE memory
+ * (*d_count <= capacity); all four buffers live on device slot `dev_slot`. */
 int  mipt_queue_bin_device(mipt_scene *, int dev_slot, const uint32_t *d_keys, const int32_t *d_vals, const int32_t *d_count,
                            int64_t capacity, int key_bits, int32_t *d_out);
 /* EnvMap::getPixelColor envMap.cuh:50-89 evaluated on the device for n directions (host buffers). */

@@ -45,7 +45,7 @@ int main(int argc, char **argv) {
             (void)hipEventRecord(e[1]); (void)hipEventSynchronize(e[1]);
             float ms; (void)hipEventElapsedTime(&ms, e[0], e[1]); if (ms < bestq) bestq = ms;
         }
-        printf("queue_sort.h two-pass binning (21 bits): %.3f ms\n", bestq);
+        printf("queue_sort.h sample-sort binning: %.3f ms\n", bestq);
 #ifdef MIPT_SORT_PROF
         {
             unsigned long long p[32];

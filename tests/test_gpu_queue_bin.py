@@ -2,9 +2,10 @@
 front of the closest-hit kernel, driven through the C-ABI (mipt_queue_bin_device) on explicit keys.
 
 Contract checked here (the order of a queue changes no result, so the stage promises coherence, not a total order): the
-output is a permutation of the input values; the top 10 key bits never decrease; inside a run of equal top-10 bits the next
-11 bits form at most ceil(len / 16384) ascending runs.  Lengths are read from device memory; edge cases: empty queue, one
-entry, all keys equal (the wave-uniform path), keys with only the top bits set, a length that is not the capacity."""
+output is a permutation of the input values; the top 14 key bits decrease at most n / 262144 times (slices of a bucket that
+one crowded key range made huge); on uniform keys neighbours are in order up to a few low bits.  Lengths are read from
+device memory; edge cases: empty queue, one entry, all keys equal (the wave-uniform path and the oversized-bin path), keys in
+one narrow range, runs of the largest key, a length that is not the capacity."""
 import numpy as np
 import pytest
 
@@ -12,7 +13,7 @@ from cuda_path_tracer_amd import generators as G
 from cuda_path_tracer_amd.scene import Scene
 
 pytestmark = pytest.mark.gpu
-CHUNK = 1 << 14
+CHUNK = 1 << 18  # kSortChunk
 
 
 @pytest.fixture(scope="module")
@@ -38,21 +39,19 @@ def _bin(scene, keys, n, key_bits, capacity=None):
     return vals, d_out.cpu().numpy()
 
 
-def _check(keys, vals, out, n, key_bits):
+def _check(keys, vals, out, n, key_bits, uniform=False):
     assert np.array_equal(out[n:], np.full(len(out) - n, -1, np.int32)), "wrote past the queue's length"
     got = out[:n]
     assert np.array_equal(np.sort(got), np.sort(vals[:n])), "not a permutation of the input"
     if n == 0:
         return
-    k = keys[(got - 7) // 3].astype(np.uint64)
-    d1 = (k >> np.uint64(key_bits - 10)) & np.uint64(1023)
-    d2 = (k >> np.uint64(key_bits - 21)) & np.uint64(2047)
-    assert np.all(np.diff(d1.astype(np.int64)) >= 0), "top 10 key bits decrease"
-    # inside each bucket: at most ceil(len / CHUNK) ascending runs of the next 11 bits
-    edges = np.flatnonzero(np.diff(d1.astype(np.int64)) != 0) + 1
-    for a, b in zip(np.r_[0, edges], np.r_[edges, n]):
-        drops = int(np.count_nonzero(np.diff(d2[a:b].astype(np.int64)) < 0))
-        assert drops <= (b - a + CHUNK - 1) // CHUNK - 1, (a, b, drops)
+    k = keys[(got - 7) // 3].astype(np.int64)
+    fine = k >> (key_bits - 14)
+    drops = int(np.count_nonzero(np.diff(fine) < 0))
+    assert drops <= n // CHUNK, (drops, n // CHUNK)
+    if uniform and n >= 8000:  # buckets span ~16-40 fine bins: ordered down to a few bits above the last one
+        assert np.diff(k).min() > -(1 << (key_bits - 19)), int(np.diff(k).min())
+    return k
 
 
 @pytest.mark.parametrize("n", [0, 1, 63, 64, 8191, 8192, 8193, 100_003, 3_000_001])
@@ -60,7 +59,7 @@ def test_random_keys(scene, n):
     rng = np.random.default_rng(n + 1)
     keys = rng.integers(0, 1 << 24, size=max(n, 1), dtype=np.uint32)
     vals, out = _bin(scene, keys, n, 24)
-    _check(keys, vals, out, n, 24)
+    _check(keys, vals, out, n, 24, uniform=True)
 
 
 def test_length_comes_from_the_device_not_the_capacity(scene):
@@ -86,7 +85,9 @@ def test_skewed_and_degenerate_keys(scene):
     }
     for name, keys in cases.items():
         vals, out = _bin(scene, keys, n, 24)
-        _check(keys, vals, out, n, 24)
+        k = _check(keys, vals, out, n, 24)
+        if name == "one huge bucket":  # 16 crowded fine bins: a bucket each, ordered down to the last bit
+            assert np.all(np.diff(k) >= 0), name
 
 
 def test_wider_keys_light_index_above_the_cell(scene):
@@ -96,4 +97,4 @@ def test_wider_keys_light_index_above_the_cell(scene):
     for light_bits in (1, 3, 8):
         keys = (rng.integers(0, 1 << light_bits, size=n, dtype=np.uint32) << np.uint32(24)) | rng.integers(0, 1 << 24, size=n, dtype=np.uint32)
         vals, out = _bin(scene, keys, n, 24 + light_bits)
-        _check(keys, vals, out, n, 24 + light_bits)
+        _check(keys, vals, out, n, 24 + light_bits, uniform=True)
