@@ -61,13 +61,13 @@ def bytes_per_ray(nodes, refs, tris, hit_frac):
 
 
 def product_bytes_per_ray(st, rays, origin_bytes=16.0, queue_bytes=4.0):
-    """What k_extend<kProd> reads and writes per ray by its own layout: per node step one 16-byte child
-    pair + one 64-byte cull-box pair; per stack pop / mesh root one 8-byte node + one 32-byte box; 32 bytes per streamed
+    """What k_extend<kProd> reads and writes per ray by its own layout: per node step ONE 64-byte step
+    record (both children's cull boxes and their 8-byte nodes); per stack pop / mesh root one 8-byte node + one 32-byte box; 32 bytes per streamed
     candidate-sphere pair; 16 bytes per marked candidate's plane + 48 for the vertices of those that reach the edge
     tests; ray in (16 direction [+ 16 origin] [+ 4 queue index] + 8 parked sphere/plane answer) and 8 hit out."""
     rays = max(1, rays)
     per = {k: st["work_" + k] / rays for k in ("steps", "pops", "sphere_pairs", "planes", "verts", "leaves")}
-    b = (80.0 * per["steps"] + 40.0 * per["pops"] + 32.0 * per["sphere_pairs"] + 16.0 * per["planes"] + 48.0 * per["verts"]
+    b = (64.0 * per["steps"] + 40.0 * per["pops"] + 32.0 * per["sphere_pairs"] + 16.0 * per["planes"] + 48.0 * per["verts"]
          + 16.0 + origin_bytes + queue_bytes + 8.0 + 8.0)
     return b, per
 
@@ -102,12 +102,21 @@ def collect_pmc(args, log):
         if rc != 0 or not os.path.exists(mf):
             return None, "pmc pass %d failed (rc %d, see %s)" % (i, rc, out)
         manifest = json.load(open(mf))["parts"]
-        rows = []
+        rows, shade_rows = [], []
         for f in glob.glob(os.path.join(out, "p%d" % i, "**", "*counter_collection.csv"), recursive=True):
             for row in csv.DictReader(open(f)):
                 name = row["Kernel_Name"]
                 if "k_extend<0>" in name or "k_extend<(int)0>" in name:
                     rows.append((int(row["Dispatch_Id"]), row["Counter_Name"], float(row["Counter_Value"])))
+                elif "k_shade" in name:  # only the C2 part of the worker shades
+                    shade_rows.append((int(row["Dispatch_Id"]), row["Counter_Name"], float(row["Counter_Value"])))
+        if shade_rows:
+            disp = {}
+            for d, c, v in shade_rows:
+                disp.setdefault(d, {})[c] = disp.get(d, {}).get(c, 0.0) + v
+            dst = sums.setdefault("c2_shade", {"launches": len(disp)})
+            for c in ctrs:
+                dst[c] = sum(x.get(c, 0.0) for x in disp.values()) / max(1, len(disp))
         by_disp = {}
         for d, c, v in rows:
             by_disp.setdefault(d, {})[c] = by_disp.get(d, {}).get(c, 0.0) + v
@@ -176,9 +185,88 @@ def roofline_views(pmc, launch_ms, rays_per_launch, alg_bpr, ref_bpr, extra=None
                   "unit": "fraction of peak VALU lane throughput (issue-slot busy x lanes active)", "frac": round(busy * lane, 4),
                   "issue_busy_frac": round(busy, 4)})
     else:
-        r.update({"bound": "hbm", "achieved": round(hbm_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                  "frac": round(hbm_gbs / HBM_PEAK_GBS, 4)})
+        r.update({"bound": "memory side (L2 miss lines, Infinity Cache included)", "achieved": round(hbm_gbs, 1), "peak": HBM_PEAK_GBS,
+                  "unit": "GB/s", "frac": round(hbm_gbs / HBM_PEAK_GBS, 4),
+                  "frac_of_measured_copy_peak": round(hbm_gbs / HBM_MEASURED_COPY_GBS, 4),
+                  "bound_note": "lines out of L2 per second against the 8 TB/s HBM peak and the 6.3 TB/s a copy reaches; part of them "
+                                "is served by the 256 MB Infinity Cache (the counters sit on the L2's memory side), so this is the "
+                                "memory-side ceiling, not an HBM fraction"})
     return r
+
+
+def shade_roofline(pmc, launch_ms, vertices_per_launch):
+    """k_shade (camera-vertex shading: surface, direct connection, roulette, BSDF sample, queue appends): the second
+    largest kernel of a render.  Memory-side bytes, VALU issue and lane use from the same PMC passes; time from HIP events."""
+    r = {"kernel": "k_shade", "avg_launch_ms": round(launch_ms, 4), "shaded_vertices_per_launch": int(round(vertices_per_launch))}
+    if not pmc or launch_ms <= 0:
+        r.update({"bound": "hbm", "frac": None, "traffic": None, "note": "no PMC counters in this run"})
+        return r
+    sec = launch_ms * 1e-3
+    traffic = pmc["TCC_MISS_sum"] * LINE_BYTES
+    gbs = traffic / sec / 1e9
+    busy = 4.0 * pmc["SQ_ACTIVE_INST_VALU"] / (pmc["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0)
+    lane = pmc["SQ_THREAD_CYCLES_VALU"] / (64.0 * pmc["SQ_ACTIVE_INST_VALU"])
+    r.update({"hbm": {"achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
+                      "frac_of_measured_copy_peak": round(gbs / HBM_MEASURED_COPY_GBS, 4),
+                      "bytes_per_shaded_vertex": round(traffic / max(1.0, vertices_per_launch), 1),
+                      "l2_hit_rate": round(pmc["TCC_HIT_sum"] / max(1.0, pmc["TCC_HIT_sum"] + pmc["TCC_MISS_sum"]), 4),
+                      "fetch_size_x2_bytes": int(round(pmc["FETCH_SIZE"] * 1024.0 * 2.0)), "write_size_bytes": int(round(pmc["WRITE_SIZE"] * 1024.0))},
+              "valu": {"busy_frac": round(busy, 4), "lane_use": round(lane, 4), "useful_lane_frac": round(busy * lane, 4),
+                       "insts_per_shaded_vertex": round(pmc["SQ_INSTS_VALU"] * 64.0 * lane / max(1.0, vertices_per_launch), 1)},
+              "traffic": int(round(traffic))})
+    if busy >= gbs / HBM_MEASURED_COPY_GBS:
+        r.update({"bound": "valu", "achieved": round(busy * lane, 4), "peak": 1.0, "unit": "fraction of peak VALU lane throughput", "frac": round(busy * lane, 4)})
+    else:
+        r.update({"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4)})
+    return r
+
+
+# ----------------------------------------------------------------------------------------------- the other BASELINE configurations
+def env_faces_1024(G):
+    rng = np.random.Generator(np.random.Philox(key=G.SEED))
+    base = rng.random((6, 64, 64, 3), dtype=np.float32)
+    return np.ascontiguousarray(np.repeat(np.repeat(base, 16, axis=1), 16, axis=2)) * np.float32(2.0)
+
+
+def other_config(name, G, cube):
+    """(scene description, render keywords, text) of BASELINE.json configs C1, C3, C4, C5 at a bounded sample count (samples are
+    independent, so samples/s does not depend on spp)."""
+    if name == "C1":
+        return G.scene_default(cube), dict(width=640, height=480, spp=16, cam_depth=6, light_depth=0), "default scene, simple d6, 640x480, 16 spp"
+    if name == "C3":
+        return G.scene_default(cube), dict(width=1024, height=1024, spp=200, cam_depth=3, light_depth=3), "default scene, bidirectional 3+3, 1024x1024, 200 spp"
+    if name == "C4":
+        return (G.scene_env_sphere(8, env_f32=env_faces_1024(G)), dict(width=3840, height=2160, spp=16, cam_depth=6, light_depth=0, use_envmap=True),
+                "env map + icosphere L8 (1,310,720 tris), simple d6, 4K, 16 of 1024 spp")
+    if name == "C5":
+        return (G.scene_multi_sphere(8), dict(width=3840, height=2160, spp=4, cam_depth=5, light_depth=5),
+                "8 x icosphere L8 (10,485,760 tris), bidirectional 5+5, 4K, 4 of 4096 spp")
+    raise KeyError(name)
+
+
+def run_other_config(name, G, Scene, make_config, device=0):
+    import tempfile as _tf
+    cube = G.write_cube_obj(os.path.join(_tf.mkdtemp(), "cube.obj"))
+    desc, kw, text = other_config(name, G, cube)
+    t0 = time.time()
+    s = desc.apply(Scene())
+    s.commit((device,))
+    t_commit = time.time() - t0
+    s.render(make_config(**{**kw, "sample_end": 1}))  # warm-up: one sample per pixel
+    t0 = time.time()
+    img, st = s.render(make_config(**kw))
+    wall = time.time() - t0
+    out = {"config": name, "workload": text, "samples_per_sec": round(st["samples"] / (st["ms_total"] * 1e-3), 1),
+           "Mrays_per_s": round(st["rays_total"] / (st["ms_total"] * 1e-3) / 1e6, 1),
+           "rays_per_sample": round(st["rays_total"] / st["samples"], 2), "ms_gpu": round(st["ms_total"], 1),
+           "extend_share": round(st["ms_extend"] / st["ms_total"], 3), "shade_share": round(st["ms_shade"] / st["ms_total"], 3),
+           "wall_s_incl_readback": round(wall, 3),
+           "commit_s": round(t_commit, 2), "kd_build_s": round(s.kd_seconds(), 2), "pack_s": round(s.build_seconds() - s.kd_seconds(), 2),
+           "arena_MB": round(s.device_bytes() / 1e6, 1),
+           "image_mean_finite_pixels": float(img[np.isfinite(img).all(axis=2)].mean()),
+           "nonfinite_pixels": int((~np.isfinite(img).all(axis=2)).sum()), "nonfinite_samples": int(st["nonfinite_samples"])}
+    s.close()
+    return out
 
 
 # ----------------------------------------------------------------------------------------------- closest hit
@@ -296,6 +384,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 --pmc child passes (roofline.frac is then withheld)")
     ap.add_argument("--no-strong", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the short runs of BASELINE configs C1, C3, C4, C5 (N=1 only)")
     ap.add_argument("--pmc-timeout", type=float, default=150.0)
     ap.add_argument("--save-pmc", default=None, help="write the per-launch counter means of the PMC passes to this JSON file")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -332,10 +421,17 @@ def main():
                       open(args.save_pmc, "w"), indent=1)
         if pmc is None:
             log("PMC collection failed: " + pmc_source)
-            fallback = os.path.join(ROOT, "profiles", "r2_pmc_bench.json")
+            fallback = os.path.join(ROOT, "profiles", "r3_pmc_bench.json")
             if os.path.exists(fallback):
                 pmc = json.load(open(fallback))["parts"]
-                pmc_source = "profiles/r2_pmc_bench.json (committed; live collection failed: %s)" % pmc_source
+                pmc_source = "profiles/r3_pmc_bench.json (committed; live collection failed: %s)" % pmc_source
+    elif world > 1:
+        # a scaling run collects no counters (N ranks under a profiler each): its roofline object carries the committed N = 1
+        # counters, labelled as such, scaled to this run's launch shape and timed by this run's own HIP events
+        committed = os.path.join(ROOT, "profiles", "r3_pmc_bench.json")
+        if os.path.exists(committed):
+            pmc = json.load(open(committed))["parts"]
+            pmc_source = "profiles/r3_pmc_bench.json: counters of the committed N = 1 run (a run at N > 1 collects none); launch times are this run's"
 
     import torch
     import torch.distributed as dist
@@ -419,7 +515,7 @@ def main():
     elapsed, steps = timed(spp_total, S * world, accum)
     assert len(steps) == K
     tot = {k: sum(st[k] for st in steps) for k in ("rays_total", "rays_extended", "ms_extend", "ms_total", "extend_launches",
-                                                    "samples", "rays_camera", "rays_shadow", "nonfinite_samples")}
+                                                    "samples", "rays_camera", "rays_shadow", "nonfinite_samples", "ms_shade", "shade_launches")}
     img_mean = float(accum.mean().item())
     strong = None
     if world > 1 and not args.no_strong:
@@ -453,14 +549,18 @@ def main():
             "rays_through_extend_frac": round(tot["rays_extended"] / max(1, tot["rays_total"]), 4),
             "Mrays_per_s_rank0": round(tot["rays_total"] / elapsed / 1e6, 1),
             "extend_share_of_gpu_time": round(tot["ms_extend"] / max(1e-9, tot["ms_total"]), 3),
+            "shade_share_of_gpu_time": round(tot["ms_shade"] / max(1e-9, tot["ms_total"]), 3),
             "image_mean": round(img_mean, 6), "nonfinite_samples": tot["nonfinite_samples"],
-            "scene_seconds": round(t_build, 3),
+            "scene_seconds": round(t_build, 3), "commit_s": round(t_build, 3),
+            "commit_note": "kd build + pack + upload of the C2 scene (81,920 triangles: built and packed on the host, below the GPU builders' threshold); the large meshes' commit times are in closest_hit.commit_s and other_configs[].commit_s",
             "roofline": roofline_views(pmc.get("c2") if pmc else None, tot["ms_extend"] / launches, tot["rays_extended"] / launches,
                                        alg_bpr, ref_bpr,
                                        {"launches": tot["extend_launches"], "pmc_source": pmc_source,
                                         "reference_walk_per_ray": {k: round(v, 2) for k, v in means.items()},
                                         "product_walk_per_ray": {k: round(v, 2) for k, v in per.items()}}),
         }
+        line["roofline_k_shade"] = shade_roofline(pmc.get("c2_shade") if pmc else None, tot["ms_shade"] / max(1, tot["shade_launches"]),
+                                                  tot["rays_camera"] / max(1, tot["shade_launches"]))
         if strong is not None:
             line["strong"] = strong
         if not args.no_cpu_baseline and world == 1:
@@ -486,9 +586,27 @@ def main():
                 "seconds": round(t_cpu, 2),
                 "per_ray": {k: round(octr[k] / max(1, octr["rays"]), 2) for k in ("nodes", "refs", "tris")},
             }
+        if world > 1:
+            committed = os.path.join(ROOT, "profiles", "r3_bench_default.json")
+            if os.path.exists(committed):
+                try:
+                    cb = json.load(open(committed)).get("cpu_baseline")
+                except ValueError:
+                    cb = None
+                if cb:
+                    line["cpu_baseline"] = dict(cb, source="profiles/r3_bench_default.json: timed in the committed N = 1 run (the CPU leg runs on rank 0 at N = 1 only)")
         if not args.no_closest and world == 1:
             del scratch
             line["closest_hit"] = closest_hit_bench(torch, G, Scene, args.closest_rays, not args.no_cpu_baseline, pmc)
+        if not args.no_other_configs and world == 1:
+            scene.close()
+            del accum
+            torch.cuda.empty_cache()
+            line["other_configs"] = []
+            for name in ("C1", "C3", "C4", "C5"):
+                t1 = time.time()
+                line["other_configs"].append(run_other_config(name, G, Scene, make_config, local_rank))
+                log("%s: %.1f s" % (name, time.time() - t1))
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

@@ -26,7 +26,7 @@ class Stats(C.Structure):
         ("ctr_nodes", C.c_int64), ("ctr_pops", C.c_int64), ("ctr_refs", C.c_int64), ("ctr_tris", C.c_int64),
         ("ctr_hits", C.c_int64), ("ctr_culled", C.c_int64), ("nonfinite_samples", C.c_int64),
         ("work_steps", C.c_int64), ("work_pops", C.c_int64), ("work_sphere_pairs", C.c_int64), ("work_planes", C.c_int64),
-        ("work_verts", C.c_int64), ("work_leaves", C.c_int64),
+        ("work_verts", C.c_int64), ("work_leaves", C.c_int64), ("shade_launches", C.c_int64), ("ms_shade", C.c_double),
     ]
 
     def as_dict(self):

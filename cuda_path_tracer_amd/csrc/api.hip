@@ -566,6 +566,8 @@ int mipt_render(mipt_scene *s, const mipt_render_config *cfg, float *out, mipt_s
             st->ms_total = std::max(st->ms_total, o.ms_total);
             st->ms_extend = std::max(st->ms_extend, o.ms_extend);
             st->ms_other = std::max(st->ms_other, o.ms_other);
+            st->shade_launches += o.shade_launches;
+            st->ms_shade = std::max(st->ms_shade, o.ms_shade);
         }
     }
     return 0;

@@ -815,7 +815,7 @@ int wavefront_render(const HostScene &hs, DeviceCtx &dc, const mipt_render_confi
     b.q_light_key = sort_light ? dc.wf[34].as<uint32_t>() : nullptr;
 
     dc.events.reset();
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> ext_ev;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ext_ev, shade_ev;
     hipStream_t sm = dc.stream;
     WF_TRY(hipMemsetAsync(dc.wf[17].p, 0, sizes[17], sm));
     const int mode = extend_mode(cfg.flags);
@@ -874,7 +874,13 @@ int wavefront_render(const HostScene &hs, DeviceCtx &dc, const mipt_render_confi
         for (int i = 0; i < Dc; i++) {
             extend((i == 0 && pp.common_origins) ? nullptr : b.st_o[i & 1], b.st_d[i & 1], b.q_ext_cam,
                    &b.counts[kCntPad * (kCntExtCam + i)], b.st_hit[i & 1], np, i == 0, (i == 0 && pp.common_origins) ? 1 : 0);
-            hipLaunchKernelGGL(k_shade, dim3(path_grid), dim3(kBlock), 0, sm, dc.view, pp, b, i);
+            {
+                hipEvent_t a = dc.events.next(), e = dc.events.next();
+                (void)hipEventRecord(a, sm);
+                hipLaunchKernelGGL(k_shade, dim3(path_grid), dim3(kBlock), 0, sm, dc.view, pp, b, i);
+                (void)hipEventRecord(e, sm);
+                shade_ev.emplace_back(a, e);
+            }
             const int *shadow_queue = b.q_shadow;
             if (sort_shadow && i >= dc.shadow_sort_from)
                 sort_queue(b.q_shadow_key, b.q_shadow, kCntShadow + i, kShadowKeyBits, shadow_queue);
@@ -934,6 +940,14 @@ int wavefront_render(const HostScene &hs, DeviceCtx &dc, const mipt_render_confi
         st->ms_total = ms;
         st->ms_extend = ms_ext;
         st->ms_other = ms - ms_ext;
+        double ms_shade = 0.0;
+        for (auto &pr : shade_ev) {
+            float m = 0.f;
+            WF_TRY(hipEventElapsedTime(&m, pr.first, pr.second));
+            ms_shade += m;
+        }
+        st->shade_launches = (int64_t)shade_ev.size();
+        st->ms_shade = ms_shade;
         if (count_mode) {
             unsigned long long c[8] = {0};
             WF_TRY(hipMemcpy(c, dc.counters.p, sizeof(c), hipMemcpyDeviceToHost));

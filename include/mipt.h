@@ -52,12 +52,15 @@ typedef struct mipt_stats {
      * sqrt of a tiny negative, samplers.cuh:19, kernel.cu:254,276; such a sample poisons image[id], kernel.cu:343) */
     int64_t nonfinite_samples;
     /* what the PRODUCTION closest-hit kernel read, filled only with MIPT_FLAG_WORK_COUNTERS (same results, slower): */
-    int64_t work_steps;      /* node steps: one 16-byte child pair + one 64-byte cull-box pair each            */
+    int64_t work_steps;      /* node steps: one 64-byte step record each (both children's cull boxes and nodes)  */
     int64_t work_pops;       /* stack pops + mesh roots opened: one 8-byte node + one 32-byte box each         */
     int64_t work_sphere_pairs; /* 32-byte candidate-sphere pairs streamed by the leaf scans                    */
     int64_t work_planes;     /* marked candidates: one 16-byte plane record each                               */
     int64_t work_verts;      /* of those, candidates that reached the edge tests: 48 bytes of vertices each    */
     int64_t work_leaves;     /* leaf scans (one 4-byte reference -> triangle id lookup per scan with a hit)    */
+    /* the second-largest kernel of a render, timed like the closest-hit launches (HIP events on the scene's stream): */
+    int64_t shade_launches;  /* launches of the camera-vertex shading kernel (one per camera vertex and pass)   */
+    double ms_shade;         /* their summed GPU time (part of ms_other)                                        */
 } mipt_stats;
 
 enum {

@@ -42,6 +42,7 @@ class OrcSampleProbe(C.Structure):
 
 
 _lib = None
+_variants = {}
 _VP = C.c_void_p
 _F3 = C.POINTER(C.c_float)
 
@@ -50,13 +51,23 @@ def build():
     subprocess.check_call(["make", "-s", "-C", _HERE])
 
 
-def load():
+# Mutation switches of the -DORC_MUTATIONS builds (bit numbers: enum MUT_* in oracle.cpp); "fma" is not a bit but a build:
+# liboracle_mut_fma.so is the same source compiled with -ffp-contract=fast.
+MUTATIONS = ("q5_minx_eps", "q10_shadow_from_hit", "q13_sampled_light", "q14_no_overwrite", "q15_single_cos", "q16_roulette_pdf",
+             "q1_exact_normalize", "dev7_unfused", "q12_uniform_emission", "q11_keep_camera_path", "q3_normalised_parallel")
+
+
+def load(variant=""):
+    """variant: "" = the checker (liboracle.so); "mut" / "mut_fma" = the builds with the quirk switches (mutation tests)."""
     global _lib
-    if _lib is not None:
+    if variant == "" and _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
+    if variant in _variants:
+        return _variants[variant]
+    path = LIB_PATH if variant == "" else os.path.join(_HERE, "liboracle_%s.so" % variant)
+    if not os.path.exists(path):
         build()
-    lib = C.CDLL(LIB_PATH)
+    lib = C.CDLL(path)
     lib.orc_scene_create.restype = _VP
     lib.orc_last_error.restype = C.c_char_p
     for name in ("orc_triangle_intersect", "orc_box_intersect", "orc_plane_intersect", "orc_sphere_intersect",
@@ -92,8 +103,22 @@ def load():
     lib.orc_env_lookup.argtypes = [_VP, _VP, C.c_int64, _VP, _VP, _VP]
     lib.orc_hdr_load.argtypes = [C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int), _VP]
     lib.orc_srt_matrix.argtypes = [_F3, _F3, _F3, _VP, _VP]
-    _lib = lib
+    lib.orc_set_mutations.argtypes = [C.c_uint32]
+    _variants[variant] = lib
+    if variant == "":
+        _lib = lib
     return lib
+
+
+def set_mutations(names, variant="mut"):
+    """Switch the named quirks (MUTATIONS) of a mutation build; () restores the reference's behaviour.  The mask is global
+    to that library: one render at a time."""
+    mask = 0
+    for n in names:
+        mask |= 1 << MUTATIONS.index(n)
+    lib = load(variant)
+    if lib.orc_set_mutations(mask) < 0:
+        raise OracleError(lib.orc_last_error().decode(errors="replace"))
 
 
 def _f3(v):
@@ -117,8 +142,8 @@ def _check(rc):
 class OracleScene:
     """Same method names as cuda_path_tracer_amd.scene.Scene, evaluated by the CPU restatement."""
 
-    def __init__(self, threads=0):
-        self._lib = load()
+    def __init__(self, threads=0, variant=""):
+        self._lib = load(variant)
         self._h = C.c_void_p(self._lib.orc_scene_create())
         self.threads = int(threads)
 

@@ -49,6 +49,32 @@ constexpr int MAX_DEPTH = 16;  // upper bound on cam_depth / light_depth accepte
 
 thread_local std::string g_err;
 
+// ---- mutation switches (tests/test_pin_mutations.py, scripts/pin_mutations.py) -------------------------------------------
+// The only reference-held pin of this restatement is image-level (two README renders).  To show what that pin can and cannot
+// see, every quirk of SURVEY.md 8.1 that the integrator depends on can be flipped to what a "clean" implementation would do,
+// one at a time.  Compiled in only with -DORC_MUTATIONS (oracle/liboracle_mut.so): in the normal build MUT() is a constant
+// false and the checker's arithmetic and speed are untouched.
+enum {
+    MUT_Q5_MINX_EPS = 0,       // isVertexInBox: give min-X the +eps slack of the other five bounds (mesh.cuh:132)
+    MUT_Q10_SHADOW_FROM_HIT,   // direct connection: shadow ray from the surface point towards the light (kernel.cu:248)
+    MUT_Q13_SAMPLED_LIGHT,     // direct connection to the sampled light instead of lights[0] (kernel.cu:244,250)
+    MUT_Q14_NO_OVERWRITE,      // a stored light vertex keeps the throughput that ARRIVES at it (kernel.cu:213-222)
+    MUT_Q15_SINGLE_COS,        // connection weight with cosCam once (kernel.cu:276)
+    MUT_Q16_ROULETTE_PDF,      // roulette probability not folded into the path pdf (kernel.cu:287-296)
+    MUT_Q1_EXACT_NORMALIZE,    // normalize() divides by |v|, no +eps (math.cuh:28)
+    MUT_DEV7_UNFUSED,          // ray_at as the source text says: product, then sum, two roundings (deviation 7 off)
+    MUT_Q12_UNIFORM_EMISSION,  // light emission direction uniform on the sphere (light.cuh:35-38)
+    MUT_Q11_KEEP_CAMERA_PATH,  // a first light ray that hits nothing does not end the sample (kernel.cu:185)
+    MUT_Q3_NORMALISED_PARALLEL,// triangle parallel test on the unit normal (mesh.cuh:48-50)
+    MUT_COUNT
+};
+#ifdef ORC_MUTATIONS
+uint32_t g_mut = 0u;
+#define MUT(bit) (((g_mut >> (bit)) & 1u) != 0u)
+#else
+#define MUT(bit) false
+#endif
+
 // ---------------------------------------------------------------- math/math.cuh:18-47
 struct V3 {
     float x = 0.f, y = 0.f, z = 0.f;
@@ -65,7 +91,7 @@ inline V3 cross(V3 a, V3 b) {                                               // m
     return mk(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
 }
 inline float length(V3 a) { return sqrtf(a.x * a.x + a.y * a.y + a.z * a.z); }  // math.cuh:29
-inline V3 normalize(V3 a) { return a * (1 / (length(a) + EPS)); }             // math.cuh:28 (Q1)
+inline V3 normalize(V3 a) { return a * (1 / (length(a) + (MUT(MUT_Q1_EXACT_NORMALIZE) ? 0.0f : EPS))); }  // math.cuh:28 (Q1)
 inline float average(V3 a) { return (a.x + a.y + a.z) / 3.0f; }               // math.cuh:30
 inline float axis_of(V3 a, int ax) { return ax == 0 ? a.x : (ax == 1 ? a.y : a.z); }
 
@@ -143,7 +169,10 @@ inline Ray make_ray(V3 o, V3 dir) { Ray r; r.o = o; r.d = normalize(dir); return
 // multiply-add that nvcc's default -fmad=true makes of a product feeding a sum.  The only contraction of the reference's
 // build that its published renders show (tests/test_oracle_golden.py, DESIGN.md 2 deviation 7); everything else in this
 // file is compiled with -ffp-contract=off.
-inline V3 ray_at(const Ray &r, float t) { return mk(fmaf(r.d.x, t, r.o.x), fmaf(r.d.y, t, r.o.y), fmaf(r.d.z, t, r.o.z)); }
+inline V3 ray_at(const Ray &r, float t) {
+    if (MUT(MUT_DEV7_UNFUSED)) return r.o + r.d * t;
+    return mk(fmaf(r.d.x, t, r.o.x), fmaf(r.d.y, t, r.o.y), fmaf(r.d.z, t, r.o.z));
+}
 struct Hit {  // hit.cuh:9-15 (+ prim id)
     float t = -1.0f;
     V3 pos, nrm;
@@ -174,7 +203,7 @@ struct Box {  // mesh.cuh:115-127; lo/hi[axis]
 
 // mesh.cuh:131-139 (Q5: min-X has no epsilon, every other bound has +eps slack)
 inline bool box_contains(const Box &b, V3 p) {
-    return (b.lo[0] <= p.x && p.x <= b.hi[0] + EPS && b.lo[1] <= p.y + EPS && p.y <= b.hi[1] + EPS &&
+    return (b.lo[0] <= p.x + (MUT(MUT_Q5_MINX_EPS) ? EPS : 0.0f) && p.x <= b.hi[0] + EPS && b.lo[1] <= p.y + EPS && p.y <= b.hi[1] + EPS &&
             b.lo[2] <= p.z + EPS && p.z <= b.hi[2] + EPS);
 }
 // mesh.cuh:141-146 (Q6: at least one vertex inside)
@@ -203,7 +232,7 @@ inline float tri_intersect_t(const Tri &tr, const Ray &r) {
     V3 ab = tr.pb - tr.pa, ac = tr.pc - tr.pa;
     V3 N = cross(ab, ac);
     float nd = dot(N, r.d);
-    if (fabsf(nd) < EPS) return -1.0f;  // :49 (hit.t keeps its default -1)
+    if (MUT(MUT_Q3_NORMALISED_PARALLEL) ? fabsf(nd) < EPS * length(N) : fabsf(nd) < EPS) return -1.0f;  // :49 (hit.t keeps its default -1)
     float d = -dot(N, tr.pa);
     float t = -(dot(N, r.o) + d) / nd;
     if (t < 0.0f) return t;  // :56 raw negative
@@ -774,6 +803,10 @@ inline V3 light_sample_dir(Rng &rng) {
     V3 X = mk(0, 0, 1), Y = mk(0, 1, 0), Z = mk(1, 0, 0);
     float alpha = rng.u() * 2.0f * PI;
     float beta = rng.u() * 2.0f * PI;
+    if (MUT(MUT_Q12_UNIFORM_EMISSION)) {  // same two draws: azimuth alpha, cos(polar) uniform in [-1, 1)
+        const float cz = 1.0f - beta / PI, sz = sqrtf(fmaxf(0.0f, 1.0f - cz * cz));
+        return normalize((X * fixed_cosf(alpha) + Z * fixed_sinf(alpha)) * sz + Y * cz);
+    }
     return normalize((X * fixed_cosf(alpha) + Z * fixed_sinf(alpha)) * fixed_sinf(beta) + Y * fixed_cosf(beta));
 }
 // samplers.cuh:8-23 (rejection sampling in the unit disc; frame from N)
@@ -836,17 +869,19 @@ V3 trace_sample(const orc_scene &sc, const orc_render_config &cfg, Ray cam_ray, 
     V3 out = mk(0, 0, 0);
     const int Dl = cfg.light_depth, Dc = cfg.cam_depth;
     LightVertex L[MAX_DEPTH];
+    int direct_light = 0;  // Q13: always lights[0]
     if (Dl > 0) {
         const int nl = (int)sc.lights.size();
         int li = (int)(rng.u() * ((float)nl));  // :178
         if (li >= nl) li = nl - 1;              // Q17 clamp (documented deviation)
         V3 ldir = light_sample_dir(rng);        // :180
         Hit h = first_intersect(sc, make_ray(sc.lights[li].loc, ldir), c);  // :183-184
-        if (h.t < 0) return out;                // :185 (Q11)
+        if (h.t < 0 && !MUT(MUT_Q11_KEEP_CAMERA_PATH)) return out;  // :185 (Q11)
+        direct_light = MUT(MUT_Q13_SAMPLED_LIGHT) ? li : 0;
         L[0].hit = h;
-        L[0].T = radiance_at(sc.lights[li], h.pos);
+        if (h.t >= 0) L[0].T = radiance_at(sc.lights[li], h.pos);
         L[0].pdf = (1.0f / (float)nl) * (1.0f / (4.0f * PI));
-        for (int i = 0; i < Dl - 1; i++) {  // :197-231
+        for (int i = 0; i < Dl - 1 && h.t >= 0; i++) {  // :197-231
             const Material &m = sc.mats[L[i].hit.mat];
             float pd = average(m.kd), pm = average(m.ks);
             float rnd = rng.u();
@@ -869,6 +904,7 @@ V3 trace_sample(const orc_scene &sc, const orc_render_config &cfg, Ray cam_ray, 
             if (nh.t < 0) break;
             L[i + 1].hit = nh;
             L[i + 1].pdf = L[i].pdf * pdf_b;
+            if (MUT(MUT_Q14_NO_OVERWRITE)) L[i + 1].T = L[i].T;  // (then :213-222 at i + 1 reads the same value from slot i)
             if (g_probe && L[i + 1].pdf == 0.0f) g_probe->zero_pdf_vertices++;
         }
     }
@@ -882,11 +918,18 @@ V3 trace_sample(const orc_scene &sc, const orc_render_config &cfg, Ray cam_ray, 
         }
         const Material &m = sc.mats[hit.mat];
         {  // direct connection to lights[0] (Q13), shadow ray cast FROM the light (Q10)  :244-257
-            V3 lp = sc.lights[0].loc;
+            V3 lp = sc.lights[direct_light].loc;
             V3 ld = normalize(hit.pos - lp);
-            Hit sh = first_intersect(sc, make_ray(lp, ld), c);
-            if (sh.t > 0 && length(sh.pos - hit.pos) < EPS) {
-                V3 lr = radiance_at(sc.lights[0], hit.pos);
+            bool visible;
+            if (MUT(MUT_Q10_SHADOW_FROM_HIT)) {  // from the surface towards the light: nothing in front of the light
+                Hit sh = first_intersect(sc, make_ray(hit.pos + hit.nrm * EPS, lp - hit.pos), c);
+                visible = sh.t < 0 || sh.t > length(lp - hit.pos) - EPS;
+            } else {
+                Hit sh = first_intersect(sc, make_ray(lp, ld), c);
+                visible = sh.t > 0 && length(sh.pos - hit.pos) < EPS;
+            }
+            if (visible) {
+                V3 lr = radiance_at(sc.lights[direct_light], hit.pos);
                 float ct = dot(hit.nrm, neg(ld));
                 if (ct > EPS) {
                     V3 brdf = m.kd / PI;
@@ -909,7 +952,7 @@ V3 trace_sample(const orc_scene &sc, const orc_render_config &cfg, Ray cam_ray, 
             if (cc < EPS || cl < EPS) continue;
             float G = cc * cl / (dist * dist);
             V3 brdf = m.kd / PI;
-            V3 cw = Tc * brdf * cc / pc;
+            V3 cw = MUT(MUT_Q15_SINGLE_COS) ? Tc * brdf / pc : Tc * brdf * cc / pc;
             V3 lw = L[j].T / L[j].pdf;
             if (g_probe && !g_probe->first_cause && !finite3(lw * G * cw)) {
                 // kernel.cu:277 light_throughput[j] / light_pdf[j]; :274 G = cosCam cosLight / dist^2; :276 camera_weight
@@ -928,11 +971,11 @@ V3 trace_sample(const orc_scene &sc, const orc_render_config &cfg, Ray cam_ray, 
             float ct = dot(hit.nrm, od);
             if (ct < EPS) break;
             Tc = Tc * m.kd / PI * ct;
-            pc = pc * pdf * pd;
+            pc = MUT(MUT_Q16_ROULETTE_PDF) ? pc * pdf : pc * pdf * pd;
         } else if (rnd < pd + pm) {
             float pdf = sample_mirror(hit.nrm, cam_ray.d, od);
             Tc = Tc * m.ks;
-            pc = pc * pdf * pm;
+            pc = MUT(MUT_Q16_ROULETTE_PDF) ? pc * pdf : pc * pdf * pm;
         } else {
             break;
         }
@@ -1001,6 +1044,17 @@ int read_obj(const char *path, const M4 &srt, std::vector<Tri> &out) {
 extern "C" {
 
 const char *orc_last_error(void) { return g_err.c_str(); }
+// Mutation mask (bit i = MUT_* above).  Only the -DORC_MUTATIONS build honours it; the checker itself refuses a non-zero mask.
+int orc_set_mutations(uint32_t mask) {
+#ifdef ORC_MUTATIONS
+    if (mask >> MUT_COUNT) return fail("unknown mutation bit");
+    g_mut = mask;
+    return 0;
+#else
+    return mask == 0u ? 0 : fail("this build of the oracle has no mutation switches (build liboracle_mut.so)");
+#endif
+}
+int orc_mutation_count(void) { return MUT_COUNT; }
 orc_scene *orc_scene_create(void) { return new orc_scene(); }
 void orc_scene_destroy(orc_scene *s) { delete s; }
 

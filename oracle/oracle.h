@@ -117,6 +117,10 @@ int orc_hdr_load(const char *path, int *w, int *h, float *cols /* may be NULL */
 void orc_srt_matrix(const float scale[3], const float rotate[3], const float translate[3], float m16[16],
                     float inv_t16[16]);
 const char *orc_last_error(void);
+/* Mutation tests (tests/test_pin_mutations.py): bit i flips quirk i (enum MUT_* in oracle.cpp) to what a clean implementation
+ * would do.  Honoured only by the -DORC_MUTATIONS builds (liboracle_mut*.so); the checker refuses a non-zero mask. */
+int orc_set_mutations(uint32_t mask);
+int orc_mutation_count(void);
 
 #ifdef __cplusplus
 }
