@@ -66,6 +66,7 @@ SIGNATURES = {
     "mipt_queue_bin_device": (C.c_int, [_VP, C.c_int, _VP, _VP, _VP, C.c_int64, C.c_int, _VP]),
     "mipt_env_lookup": (C.c_int, [_VP, _VP, C.c_int64, _VP]),
     "mipt_scene_gpu_built_meshes": (C.c_int, [_VP]),
+    "mipt_scene_packed_on_gpu": (C.c_int, [_VP]),
     "mipt_hdr_load_rgbe": (C.c_int, [C.c_char_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), _VP]),
     "mipt_mesh_count": (C.c_int, [_VP]),
     "mipt_kd_sizes": (C.c_int, [_VP, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),

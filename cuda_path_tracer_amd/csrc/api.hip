@@ -16,6 +16,7 @@
 
 #include "device_ctx.h"
 #include "kernels_extend.h"
+#include "pack_gpu.h"
 #include "queue_sort.h"
 #include "scene_host.h"
 #include "wavefront.h"
@@ -122,6 +123,26 @@ void clamp_tuning(ExtendTuning &t) {
     t.pool1_below = std::min(65, std::max(0, t.pool1_below));
 }
 
+// A scene packed on the GPU keeps no host copy of its arena (pack_gpu.hip).  Whatever needs one on the host -- export,
+// the introspection calls, the upload to a further device slot, a re-commit -- fetches it here, once.
+int ensure_host_arena(mipt_scene *s) {
+    HostScene &h = s->host;
+    if (!h.packed || !h.arena.empty()) return 0;
+    const void *src = h.dev_arena;
+    int dev = h.dev_arena_device;
+    if (!src && !s->devs.empty()) { src = s->devs[0].arena; dev = s->devs[0].device; }
+    if (!src) return fail(-2, "the packed arena exists neither on the host nor on a device");
+    h.arena.resize(h.layout.total);
+    std::string err;
+    if (!gpu_arena_read(dev, src, h.layout.total, h.arena.data(), err)) { h.arena.clear(); return fail(-2, err); }
+    return 0;
+}
+void drop_dev_arena(HostScene &h) {
+    if (h.dev_arena) gpu_free(h.dev_arena_device, h.dev_arena);
+    h.dev_arena = nullptr;
+    h.dev_arena_device = -1;
+}
+
 int setup_device(mipt_scene *s, DeviceCtx &dc) {
     HIP_TRY(hipSetDevice(dc.device));
     hipDeviceProp_t prop;
@@ -129,9 +150,17 @@ int setup_device(mipt_scene *s, DeviceCtx &dc) {
     dc.num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     HIP_TRY(hipStreamCreateWithFlags(&dc.stream, hipStreamNonBlocking));
     HIP_TRY(hipEventCreateWithFlags(&dc.ev_entry, hipEventDisableTiming));
-    HIP_TRY(hipMalloc(&dc.arena, s->host.arena.size()));
-    HIP_TRY(hipMemcpyAsync(dc.arena, s->host.arena.data(), s->host.arena.size(), hipMemcpyHostToDevice, dc.stream));
-    HIP_TRY(hipStreamSynchronize(dc.stream));
+    if (s->host.dev_arena && s->host.dev_arena_device == dc.device) {  // packed on this device: the arena is there already
+        dc.arena = s->host.dev_arena;
+        s->host.dev_arena = nullptr;
+        s->host.dev_arena_device = -1;
+    } else {
+        if (ensure_host_arena(s) != 0) return -2;
+        HIP_TRY(hipSetDevice(dc.device));
+        HIP_TRY(hipMalloc(&dc.arena, s->host.arena.size()));
+        HIP_TRY(hipMemcpyAsync(dc.arena, s->host.arena.data(), s->host.arena.size(), hipMemcpyHostToDevice, dc.stream));
+        HIP_TRY(hipStreamSynchronize(dc.stream));
+    }
     HIP_TRY(dc.counters.reserve(kCounterBytes));
     HIP_TRY(hipMemset(dc.counters.p, 0, kCounterBytes));
     HIP_TRY(hipGetSymbolAddress((void **)&dc.noalloc_scratch, HIP_SYMBOL(scratch)));  // this device's copy of the array
@@ -193,6 +222,7 @@ void mipt_scene_destroy(mipt_scene *s) {
     if (!s) return;
     release_comms(s);
     for (DeviceCtx &dc : s->devs) release_device(dc);
+    drop_dev_arena(s->host);
     delete s;
 }
 
@@ -322,6 +352,10 @@ int mipt_scene_set_envmap_f32(mipt_scene *s, const float *faces6, int w, int h) 
 int mipt_scene_commit(mipt_scene *s, const int *device_ids, int n_devices) {
     if (!s) return fail(-1, "null scene");
     if (n_devices < 0 || (n_devices > 0 && !device_ids)) return fail(-1, "bad device list");
+    if (s->host.packed && s->host.arena.empty()) {  // a GPU-packed scene is committed again: its only copy lives on a device
+        const int rc = ensure_host_arena(s);
+        if (rc != 0) return rc;
+    }
     release_comms(s);
     for (DeviceCtx &dc : s->devs) release_device(dc);
     s->devs.clear();
@@ -337,8 +371,12 @@ int mipt_scene_commit(mipt_scene *s, const int *device_ids, int n_devices) {
         DeviceCtx dc;
         dc.device = device_ids[i];
         const int rc = setup_device(s, dc);
-        if (rc != 0) {  // nothing of a half set-up slot is kept (stream, arena, counters); earlier slots stay usable
+        if (rc != 0) {  // nothing of a half set-up slot is kept (stream, arena, counters)
             const std::string why = g_err;
+            if (s->host.arena.empty()) {  // do not lose a GPU-packed arena with the slots: fetch it while one still holds it
+                if (s->devs.empty() && dc.arena) { s->devs.push_back(dc); (void)ensure_host_arena(s); s->devs.pop_back(); }
+                else (void)ensure_host_arena(s);
+            }
             release_device(dc);
             for (DeviceCtx &d : s->devs) release_device(d);
             s->devs.clear();
@@ -346,6 +384,7 @@ int mipt_scene_commit(mipt_scene *s, const int *device_ids, int n_devices) {
         }
         s->devs.push_back(dc);
     }
+    drop_dev_arena(s->host);  // (no slot on the build device adopted it: cannot happen today, the build device is slot 0's)
     s->committed = true;
     return 0;
 }
@@ -641,6 +680,7 @@ int mipt_kd_export(mipt_scene *s, int mesh, float *boxes, int32_t *axis, int32_t
                    int32_t *count, int32_t *refs) {
     if (!s || !s->host.packed) return fail(-1, "scene not committed");
     if (mesh < 0 || mesh >= (int)s->host.meshes.size()) return fail(-1, "bad mesh index");
+    if (ensure_host_arena(s) != 0) return -2;
     const HostMesh &m = s->host.meshes[(size_t)mesh];
     const DScene v = s->host.view(s->host.arena.data());
     for (int64_t i = 0; i < m.n_nodes; i++) {
@@ -672,6 +712,7 @@ int mipt_mesh_triangles(mipt_scene *s, int mesh, float *pos9, float *nrm9) {
         return 0;
     }
     // an imported scene keeps no triangle arrays: read them back from the packed float4 records
+    if (ensure_host_arena(s) != 0) return -2;
     const DScene v = s->host.view(s->host.arena.data());
     for (int64_t i = 0; i < m.n_tris * 3; i++) {
         const f4 p = v.tri_pos[3 * m.tri_base + i], n = v.tri_nrm[3 * m.tri_base + i];
@@ -683,11 +724,13 @@ int mipt_mesh_triangles(mipt_scene *s, int mesh, float *pos9, float *nrm9) {
 
 int64_t mipt_scene_export_size(mipt_scene *s) {
     if (!s || !s->host.packed) return fail(-1, "scene not committed");
+    if (ensure_host_arena(s) != 0) return -2;
     return (int64_t)export_blob(s->host, nullptr);
 }
 
 int mipt_scene_export(mipt_scene *s, void *blob, int64_t size) {
     if (!s || !s->host.packed) return fail(-1, "scene not committed");
+    if (ensure_host_arena(s) != 0) return -2;
     if (!blob || size < (int64_t)export_blob(s->host, nullptr)) return fail(-1, "export buffer too small");
     export_blob(s->host, static_cast<uint8_t *>(blob));
     return 0;
@@ -702,11 +745,13 @@ int mipt_scene_import(mipt_scene *s, const void *blob, int64_t size) {
     std::string err;
     HostScene fresh;
     if (!import_blob(fresh, static_cast<const uint8_t *>(blob), (size_t)size, err)) return fail(-5, err);
+    drop_dev_arena(s->host);
     s->host = std::move(fresh);
     return 0;
 }
 
-int64_t mipt_scene_device_bytes(mipt_scene *s) { return s && s->host.packed ? (int64_t)s->host.arena.size() : 0; }
+int64_t mipt_scene_device_bytes(mipt_scene *s) { return s && s->host.packed ? (int64_t)s->host.layout.total : 0; }
+int mipt_scene_packed_on_gpu(mipt_scene *s) { return s ? (s->host.packed_on_gpu ? 1 : 0) : fail(-1, "null scene"); }
 double mipt_scene_build_seconds(mipt_scene *s) { return s ? s->host.build_seconds : 0.0; }
 double mipt_scene_kd_seconds(mipt_scene *s) { return s ? s->host.kd_seconds : 0.0; }
 

@@ -33,7 +33,8 @@ struct BuildNode {
 };
 void assemble_kd_tree(const std::vector<BuildNode> &tree, const int32_t *leaf_refs, KdTree &out);
 
-// The same tree built on a GPU, level by level (kd_build_gpu.hip).  Returns false and sets err on a HIP error.
-bool build_kd_tree_gpu(int device, const float *pos, int64_t n_tris, KdTree &out, std::string &err);
+// The same tree built on a GPU, level by level (kd_build_gpu.hip).  Returns false and sets err on a HIP error.  d_pos: the
+// same positions on `device` if the caller has uploaded them already (the packer keeps them for pack_gpu.hip), or null.
+bool build_kd_tree_gpu(int device, const float *pos, int64_t n_tris, KdTree &out, std::string &err, const void *d_pos = nullptr);
 
 }  // namespace mipt

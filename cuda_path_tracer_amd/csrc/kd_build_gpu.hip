@@ -251,7 +251,7 @@ __global__ __launch_bounds__(kBuildBlock) void k_iota(int *__restrict__ tris, in
 
 }  // namespace
 
-bool build_kd_tree_gpu(int device, const float *pos, int64_t n_tris, KdTree &out, std::string &err) {
+bool build_kd_tree_gpu(int device, const float *pos, int64_t n_tris, KdTree &out, std::string &err, const void *d_pos_in) {
     if (n_tris <= 0 || n_tris > (int64_t)(1u << 28)) { err = "GPU kd build: triangle count out of range"; return false; }
     KD_TRY(hipSetDevice(device));
     hipStream_t st;
@@ -280,8 +280,12 @@ bool build_kd_tree_gpu(int device, const float *pos, int64_t n_tris, KdTree &out
     }
 
     DevBuf d_pos, d_tris[2], d_owner[2], d_kl, d_kr, d_cand, d_cand_sorted, d_nodes, d_res, d_dest, d_leaf, d_temp;
-    KD_TRY(d_pos.reserve((size_t)n_tris * 36));
-    KD_TRY(hipMemcpyAsync(d_pos.p, pos, (size_t)n_tris * 36, hipMemcpyHostToDevice, st));
+    const float *pos_dev = static_cast<const float *>(d_pos_in);
+    if (!pos_dev) {
+        KD_TRY(d_pos.reserve((size_t)n_tris * 36));
+        KD_TRY(hipMemcpyAsync(d_pos.p, pos, (size_t)n_tris * 36, hipMemcpyHostToDevice, st));
+        pos_dev = d_pos.as<float>();
+    }
     // a reference list never holds a triangle twice, a level's lists together can: sized as they grow (DevBuf::reserve)
     size_t leaf_cap = (size_t)n_tris * 2 + 1024;
     KD_TRY(d_leaf.reserve(leaf_cap * 4));
@@ -321,7 +325,7 @@ bool build_kd_tree_gpu(int device, const float *pos, int64_t n_tris, KdTree &out
         KD_TRY(d_cand_sorted.reserve((size_t)n_refs * 24));
         KD_TRY(hipMemcpyAsync(d_nodes.p, h_nodes.data(), (size_t)n_nodes * sizeof(LevelNode), hipMemcpyHostToDevice, st));
         hipLaunchKernelGGL(k_keys, dim3((unsigned)((n_refs + kBuildBlock - 1) / kBuildBlock)), dim3(kBuildBlock), 0, st,
-                           d_pos.as<float>(), d_nodes.as<LevelNode>(), d_tris[cur].as<int>(), d_owner[cur].as<int>(), n_refs,
+                           pos_dev, d_nodes.as<LevelNode>(), d_tris[cur].as<int>(), d_owner[cur].as<int>(), n_refs,
                            d_kl.as<float>(), d_kr.as<float>(), d_cand.as<unsigned long long>());
         {
             int owner_bits = 1;

@@ -6,6 +6,7 @@
 //   (OBJ / SRT and Radiance RGBE readers: assets.cpp)
 //   copyToDevice call sites    copyToDevice/copyToDevice.h:8-55 -> ONE arena, uploaded by api.hip
 #include "scene_host.h"
+#include "pack_gpu.h"
 
 #include <algorithm>
 #include <atomic>
@@ -69,14 +70,21 @@ bool HostScene::pack(int n_threads, std::string &err) {
     total_tris = total_nodes = total_refs = 0;
     for (const HostMesh &hm : meshes)
         if (hm.n_tris <= 0) { err = "empty mesh"; return false; }
+    // positions of the large meshes go to the device ONCE: the GPU kd build reads them there and the GPU packer after it
+    std::vector<void *> d_pos(meshes.size(), nullptr);
+    struct PosGuard {
+        std::vector<void *> &v; int dev;
+        ~PosGuard() { for (void *p : v) gpu_free(dev, p); }
+    } pos_guard{d_pos, build_device};
+    constexpr int64_t kGpuBuildMinTris = 16384;  // below that the host build takes a few milliseconds
     {
-        constexpr int64_t kGpuBuildMinTris = 16384;  // below that the host build takes a few milliseconds
         std::vector<size_t> on_host;
         meshes_built_on_gpu = 0;
         for (size_t m = 0; m < meshes.size(); m++) {
             if (build_device >= 0 && meshes[m].n_tris >= kGpuBuildMinTris) {
                 std::string gpu_err;
-                if (build_kd_tree_gpu(build_device, meshes[m].pos.data(), meshes[m].n_tris, trees[m], gpu_err)) {
+                d_pos[m] = gpu_upload(build_device, meshes[m].pos.data(), meshes[m].pos.size() * sizeof(float), gpu_err);
+                if (d_pos[m] && build_kd_tree_gpu(build_device, meshes[m].pos.data(), meshes[m].n_tris, trees[m], gpu_err, d_pos[m])) {
                     meshes_built_on_gpu++;
                 } else {  // e.g. out of device memory: the host builder makes the identical tree, only slower
                     if (getenv("MIPT_TIMING")) fprintf(stderr, "[mipt] GPU kd build of mesh %zu failed (%s): building it on the host\n", m, gpu_err.c_str());
@@ -142,8 +150,38 @@ bool HostScene::pack(int n_threads, std::string &err) {
     const size_t env_bytes = env.present() ? (env.rgbe.empty() ? env.f32.size() * 4 : env.rgbe.size() * 4) : 0;
     L.env = section(env_bytes);
     L.total = off;
+    // The big sections [0, L.meshes).  With a device and a large mesh they are made ON that device (pack_gpu.hip: the same
+    // bytes, asserted by tests/test_gpu_kd_build.py) and the host keeps no copy of the arena; else -- or should the device
+    // refuse -- on the host threads below.  MIPT_PACK=host forces the host packer.
+    const bool force_recheck = getenv("MIPT_FORCE_RECHECK") && atoi(getenv("MIPT_FORCE_RECHECK")) != 0;
+    std::vector<float> root_tight(8 * meshes.size() + 8, 0.0f);  // root cull box of every mesh (for mesh_order)
+    if (dev_arena) { gpu_free(dev_arena_device, dev_arena); dev_arena = nullptr; }
+    packed_on_gpu = false;
+    {
+        bool large = false;
+        for (const HostMesh &hm : meshes) large |= hm.n_tris >= kGpuBuildMinTris;
+        const char *pk = getenv("MIPT_PACK");
+        if (build_device >= 0 && large && !(pk && strcmp(pk, "host") == 0)) {
+            std::vector<GpuPackMesh> gm(meshes.size());
+            for (size_t m = 0; m < meshes.size(); m++)
+                gm[m] = GpuPackMesh{meshes[m].pos.data(), meshes[m].nrm.data(), meshes[m].n_tris, &trees[m], meshes[m].tri_base,
+                                    meshes[m].node_base, meshes[m].ref_base, d_pos[m]};
+            std::string gpu_err;
+            void *d_arena = nullptr;
+            if (gpu_pack_scene(build_device, gm, L, total_refs, force_recheck, &d_arena, root_tight.data(), gpu_err)) {
+                dev_arena = d_arena;
+                dev_arena_device = build_device;
+                packed_on_gpu = true;
+            } else if (getenv("MIPT_TIMING")) {
+                fprintf(stderr, "[mipt] GPU pack failed (%s): packing on the host\n", gpu_err.c_str());
+            }
+        }
+    }
+    std::vector<uint8_t> tail(L.total - L.meshes, 0);  // the small sections behind the big ones, always made here
+    uint8_t *A = nullptr;
+    if (!packed_on_gpu) {
     arena.assign(L.total, 0);
-    uint8_t *A = arena.data();
+    A = arena.data();
     {  // slots no reference owns (padding) must never pass: R^2 = -inf
         float *ls = reinterpret_cast<float *>(A + L.leaf_spheres);
         const size_t n_pairs = (size_t)total_refs / 2 + 4;
@@ -161,7 +199,6 @@ bool HostScene::pack(int n_threads, std::string &err) {
         }
         memcpy(A + L.boxes + (size_t)hm.node_base * 32, t.boxes.data(), (size_t)hm.n_nodes * 32);
         // MIPT_FORCE_RECHECK=1 (tests): flag every interior node, so the full re-evaluation path is exercised everywhere
-        const bool force_recheck = getenv("MIPT_FORCE_RECHECK") && atoi(getenv("MIPT_FORCE_RECHECK")) != 0;
         for (int64_t i = 0; i < hm.n_nodes; i++) {  // kRecheckBit: split plane outside the node's own extent (see scene_types.h)
             const KdNode k = t.nodes[(size_t)i];
             const uint32_t ax = k.b >> 30;
@@ -360,22 +397,30 @@ bool HostScene::pack(int n_threads, std::string &err) {
             }
         }
         });
+        memcpy(root_tight.data() + 8 * m, tight, 32);
+    }
+    } else {
+        arena.clear();
+        arena.shrink_to_fit();
+    }
+    uint8_t *T = tail.data() - L.meshes;  // T + L.<small section> addresses the tail
+    for (size_t m = 0; m < meshes.size(); m++) {
+        const HostMesh &hm = meshes[m];
         DMesh dm;
         dm.root = (int32_t)hm.node_base;
         dm.tri_base = (int32_t)hm.tri_base;
         dm.n_tris = (int32_t)hm.n_tris;
         dm.material = hm.material;
-        reinterpret_cast<DMesh *>(A + L.meshes)[m] = dm;
+        reinterpret_cast<DMesh *>(T + L.meshes)[m] = dm;
     }
     {  // evaluation order of the meshes for the extend kernel (any order gives Scene::firstIntersect's answer as long
        // as equal hits go to the lower triangle id, i.e. the earlier mesh, kernel.cu:147-150)
-        int32_t *mo = reinterpret_cast<int32_t *>(A + L.mesh_order);
-        const float *tight = reinterpret_cast<const float *>(A + L.tight);
+        int32_t *mo = reinterpret_cast<int32_t *>(T + L.mesh_order);
         std::vector<int> idx(meshes.size());
         for (int ax = 0; ax < 3; ax++) {
             for (size_t m = 0; m < meshes.size(); m++) idx[m] = (int)m;
             auto centre = [&](int m) {
-                const float *b = tight + 8 * (size_t)meshes[(size_t)m].node_base;
+                const float *b = root_tight.data() + 8 * (size_t)m;
                 const float lo = b[2 * ax], hi = b[2 * ax + 1];
                 return (lo <= hi) ? 0.5f * (lo + hi) : 0.0f;  // empty mesh: anywhere
             };
@@ -383,36 +428,47 @@ bool HostScene::pack(int n_threads, std::string &err) {
             for (size_t m = 0; m < meshes.size(); m++) mo[(size_t)ax * meshes.size() + m] = (int32_t)meshes[(size_t)idx[m]].node_base;
         }
     }
-    float *sp = reinterpret_cast<float *>(A + L.spheres);
+    float *sp = reinterpret_cast<float *>(T + L.spheres);
     for (size_t i = 0; i < spheres.size(); i++) {
         const HostSphere &s = spheres[i];
         const float v[8] = {s.center[0], s.center[1], s.center[2], s.radius, i2f(s.material), 0, 0, 0};
         memcpy(sp + 8 * i, v, 32);
     }
-    float *pl = reinterpret_cast<float *>(A + L.planes);
+    float *pl = reinterpret_cast<float *>(T + L.planes);
     for (size_t i = 0; i < planes.size(); i++) {
         const HostPlane &p = planes[i];
         const float v[8] = {p.point[0], p.point[1], p.point[2], i2f(p.material), p.normal[0], p.normal[1], p.normal[2], 0};
         memcpy(pl + 8 * i, v, 32);
     }
-    float *li = reinterpret_cast<float *>(A + L.lights);
+    float *li = reinterpret_cast<float *>(T + L.lights);
     for (size_t i = 0; i < lights.size(); i++) {
         const HostLight &l = lights[i];
         const float v[8] = {l.loc[0], l.loc[1], l.loc[2], 0, l.power[0], l.power[1], l.power[2], 0};
         memcpy(li + 8 * i, v, 32);
     }
-    float *ma = reinterpret_cast<float *>(A + L.materials);
+    float *ma = reinterpret_cast<float *>(T + L.materials);
     for (size_t i = 0; i < materials.size(); i++) {
         const HostMaterial &m = materials[i];
         const float v[8] = {m.kd[0], m.kd[1], m.kd[2], 0, m.ks[0], m.ks[1], m.ks[2], 0};
         memcpy(ma + 8 * i, v, 32);
     }
-    if (env_bytes) memcpy(A + L.env, env.rgbe.empty() ? (const void *)env.f32.data() : (const void *)env.rgbe.data(), env_bytes);
+    if (env_bytes) memcpy(T + L.env, env.rgbe.empty() ? (const void *)env.f32.data() : (const void *)env.rgbe.data(), env_bytes);
     (void)f2u;
+    if (packed_on_gpu) {
+        std::string gpu_err;
+        if (!gpu_arena_write(dev_arena_device, dev_arena, L.meshes, tail.data(), tail.size(), gpu_err)) {
+            gpu_free(dev_arena_device, dev_arena);
+            dev_arena = nullptr;
+            err = gpu_err;
+            return false;
+        }
+    } else {
+        memcpy(A + L.meshes, tail.data(), tail.size());
+    }
     layout = L;
     packed = true;
     build_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-    if (getenv("MIPT_TIMING")) fprintf(stderr, "[mipt] kd trees %.3f s (%d of %d meshes on the GPU), pack %.3f s (%d threads)\n", t_trees, meshes_built_on_gpu, (int)meshes.size(), build_seconds - t_trees, n_threads);
+    if (getenv("MIPT_TIMING")) fprintf(stderr, "[mipt] kd trees %.3f s (%d of %d meshes on the GPU), pack %.3f s (%s)\n", t_trees, meshes_built_on_gpu, (int)meshes.size(), build_seconds - t_trees, packed_on_gpu ? "on the GPU" : "host threads");
     return true;
 }
 

@@ -50,7 +50,13 @@ struct HostScene {
     int meshes_built_on_gpu = 0;
     bool packed = false;
     bool imported = false;       // packed state came from mipt_scene_import: no triangle arrays on the host, nothing to rebuild
-    std::vector<uint8_t> arena;  // host copy of the device arena
+    // host copy of the device arena.  EMPTY after a commit that packed on the GPU (pack_gpu.hip): the arena then exists on the
+    // device only (dev_arena until a device slot adopts it) and is fetched when something on the host asks for it
+    // (mipt_scene_export, mipt_kd_export, a second device slot) -- api.hip: ensure_host_arena().
+    std::vector<uint8_t> arena;
+    void *dev_arena = nullptr;   // GPU-packed arena on device `dev_arena_device`, not yet adopted by a device slot
+    int dev_arena_device = -1;
+    bool packed_on_gpu = false;  // the last pack() made the big sections on the device
     ArenaLayout layout;
     int64_t total_tris = 0, total_nodes = 0, total_refs = 0;
     double build_seconds = 0.0;  // kd-trees + pack

@@ -211,6 +211,10 @@ class Scene:
         """Meshes whose kd-tree the last commit built on the GPU (the others: host threads; same tree either way)."""
         return check(self._lib.mipt_scene_gpu_built_meshes(self._h))
 
+    def packed_on_gpu(self):
+        """True when the last commit made the arena's big sections on the GPU (csrc/pack_gpu.hip)."""
+        return bool(check(self._lib.mipt_scene_packed_on_gpu(self._h)))
+
     def device_bytes(self):
         return int(self._lib.mipt_scene_device_bytes(self._h))
 

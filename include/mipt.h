@@ -154,6 +154,11 @@ int  mipt_hdr_load_rgbe(const char *path, int32_t *w, int32_t *h, uint32_t *texe
  * rather than on the host threads: meshes of >= 16,384 triangles when the commit has a device, unless MIPT_KD_BUILD=host.
  * Both builders produce the same tree, bit for bit. */
 int  mipt_scene_gpu_built_meshes(mipt_scene *);
+/* 1 when the last commit made the arena's big sections (nodes, cull boxes, step records, leaf records, triangle arrays) on the
+ * GPU (pack_gpu.hip: the replacement of copyToDevice.h:8-55 and the per-leaf uploads of mesh.cu:35-36 for scenes with a mesh of
+ * >= 16,384 triangles, unless MIPT_PACK=host), 0 when the host threads did.  The arena is the same bytes either way; a
+ * GPU-packed scene keeps no host copy of it until an export / introspection call asks for one. */
+int  mipt_scene_packed_on_gpu(mipt_scene *);
 int  mipt_mesh_count(mipt_scene *);
 int  mipt_kd_sizes(mipt_scene *, int mesh, int64_t *n_nodes, int64_t *n_refs, int64_t *n_tris);
 /* Unpacks the 8-byte nodes of one mesh: boxes n*6 (minX,maxX,minY,maxY,minZ,maxZ), axis, left/right child

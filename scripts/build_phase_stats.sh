@@ -6,4 +6,4 @@ F="-O3 -std=c++17 -fPIC -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sq
 mkdir -p /tmp/ps_build ../../variants
 hipcc --offload-arch=gfx950 $F -c api.hip -o /tmp/ps_build/api.o
 hipcc --offload-arch=gfx950 $F -c wavefront.hip -o /tmp/ps_build/wavefront.o
-hipcc --offload-arch=gfx950 -shared -fPIC -pthread /tmp/ps_build/api.o /tmp/ps_build/wavefront.o scene.o assets.o kd_build.o kd_build_gpu.o -o ../../variants/libmipt_stats.so
+hipcc --offload-arch=gfx950 -shared -fPIC -pthread /tmp/ps_build/api.o /tmp/ps_build/wavefront.o scene.o assets.o kd_build.o kd_build_gpu.o pack_gpu.o -o ../../variants/libmipt_stats.so

@@ -9,4 +9,4 @@ mkdir -p $B ../../variants
 hipcc --offload-arch=gfx950 $F -c api.hip -o $B/api.o &
 hipcc --offload-arch=gfx950 $F -c wavefront.hip -o $B/wavefront.o &
 wait
-hipcc --offload-arch=gfx950 -shared -fPIC -pthread $B/api.o $B/wavefront.o scene.o assets.o kd_build.o kd_build_gpu.o -o ../../variants/libmipt_$name.so
+hipcc --offload-arch=gfx950 -shared -fPIC -pthread $B/api.o $B/wavefront.o scene.o assets.o kd_build.o kd_build_gpu.o pack_gpu.o -o ../../variants/libmipt_$name.so
