@@ -183,12 +183,13 @@ __device__ __forceinline__ void leaf_scan_coop(const DScene &sc, bool pending, i
                 const float fhi[3] = {__shfl(cur.hi[0], p, 64), __shfl(cur.hi[1], p, 64), __shfl(cur.hi[2], p, 64)};
                 if (valid) {
                     PSTAT(ps, 6);
-                    const f4 pl = sc.leaf_planes[r];
+                    const f4 *rec = sc.leaf_recs + 4 * (size_t)r;
+                    const f4 pl = rec[0];
                     const float t = plane_candidate_nobest(pl, fo, fd, flo, fhi);
                     if (WORK) wc.planes++;
                     if (t > 0.0f) {
                         if (WORK) wc.verts++;
-                        const f4 pa = sc.leaf_verts[3 * (size_t)r], pb = sc.leaf_verts[3 * (size_t)r + 1], pc = sc.leaf_verts[3 * (size_t)r + 2];
+                        const f4 pa = rec[1], pb = rec[2], pc = rec[3];
                         if (inside_triangle(pl, mk3(pa.x, pa.y, pa.z), mk3(pb.x, pb.y, pb.z), mk3(pc.x, pc.y, pc.z), fo, fd, t))
                             atomicMin(&res[p], ((unsigned long long)as_u32(t) << 32) | (unsigned long long)(unsigned int)r);
                     }
@@ -438,7 +439,8 @@ __global__ __launch_bounds__(kExtendBlock, 5) void k_extend(DScene sc, const f4 
             PSTAT(ps, 7);
             sp--;
             node = stk.pop(sp);
-            nd = sc.nodes[node];
+            nd = sc.nodes[node];  // (the 8 bytes also ride in the parent's step record; reading them there instead -- one line of
+                                  //  `nodes` fewer per pop -- measured no gain on the incoherent batch and -0.6 % on the 1080p frame)
             load_slab(sc, node, o, d, cur);
             mask_slab(cur, o, d);
             need_pop = false;

@@ -54,7 +54,7 @@ struct ArenaPtrs {
     KdNode *nodes;
     float *boxes, *tight, *tight_pairs;
     int32_t *refs;
-    float *leaf_planes, *leaf_verts, *leaf_spheres, *tri_pos, *tri_nrm;
+    float *leaf_recs, *leaf_spheres, *tri_pos, *tri_nrm;
 };
 
 // nodes (global indices + recheck flag), boxes, the leaves' cull boxes, and which leaf owns every reference
@@ -147,13 +147,12 @@ __global__ __launch_bounds__(kPackBlock) void k_pack_refs(MeshArgs m, ArenaPtrs 
     {
         const f3 pa = mk3(v[0], v[1], v[2]), pb = mk3(v[3], v[4], v[5]), pc = mk3(v[6], v[7], v[8]);
         const f3 N = cross3(pb - pa, pc - pa);
-        float *lp = a.leaf_planes + 4 * gi;
-        lp[0] = N.x; lp[1] = N.y; lp[2] = N.z;
-        lp[3] = -dot3(N, pa);
-        float *lv = a.leaf_verts + 12 * gi;
+        float *rec = a.leaf_recs + 16 * gi;  // 64 B: plane, a, b, c
+        rec[0] = N.x; rec[1] = N.y; rec[2] = N.z;
+        rec[3] = -dot3(N, pa);
         for (int q = 0; q < 3; q++) {
-            for (int c = 0; c < 3; c++) lv[4 * q + c] = v[3 * q + c];
-            lv[4 * q + 3] = 0.0f;
+            for (int c = 0; c < 3; c++) rec[4 + 4 * q + c] = v[3 * q + c];
+            rec[4 + 4 * q + 3] = 0.0f;
         }
     }
     // candidate sphere (scene.cpp: the smaller of the triangle's smallest enclosing sphere and the sphere around
@@ -295,8 +294,7 @@ bool gpu_pack_scene(int device, const std::vector<GpuPackMesh> &meshes, const Ar
     ap.tight = reinterpret_cast<float *>(A + L.tight);
     ap.tight_pairs = reinterpret_cast<float *>(A + L.tight_pairs);
     ap.refs = reinterpret_cast<int32_t *>(A + L.refs);
-    ap.leaf_planes = reinterpret_cast<float *>(A + L.leaf_planes);
-    ap.leaf_verts = reinterpret_cast<float *>(A + L.leaf_verts);
+    ap.leaf_recs = reinterpret_cast<float *>(A + L.leaf_recs);
     ap.leaf_spheres = reinterpret_cast<float *>(A + L.leaf_spheres);
     ap.tri_pos = reinterpret_cast<float *>(A + L.tri_pos);
     ap.tri_nrm = reinterpret_cast<float *>(A + L.tri_nrm);

@@ -136,8 +136,7 @@ bool HostScene::pack(int n_threads, std::string &err) {
     L.tight = section((size_t)total_nodes * 32);
     L.tight_pairs = section((size_t)(total_nodes / 2 + 1) * 64);
     L.refs = section((size_t)total_refs * 4);
-    L.leaf_planes = section((size_t)total_refs * 16);
-    L.leaf_verts = section((size_t)total_refs * 48);
+    L.leaf_recs = section((size_t)total_refs * 64);
     L.leaf_spheres = section(((size_t)total_refs / 2 + 4) * sizeof(SpherePair));  // + padding the scan may over-read
     L.tri_pos = section((size_t)total_tris * 48);
     L.tri_nrm = section((size_t)total_tris * 48);
@@ -277,22 +276,17 @@ bool HostScene::pack(int n_threads, std::string &err) {
         for (int64_t i = 0; i < hm.n_refs; i++) refs[i] = t.refs[(size_t)i] + (int32_t)hm.tri_base;
         // leaf-ordered plane records: N = cross(b-a, c-a), dd = -dot(N, a) exactly as Triangle::intersect
         // evaluates them per candidate (mesh.cuh:40-42,52); same fp32 operations, done once here
-        float *lp = reinterpret_cast<float *>(A + L.leaf_planes) + (size_t)hm.ref_base * 4;
+        float *lr = reinterpret_cast<float *>(A + L.leaf_recs) + (size_t)hm.ref_base * 16;  // 64 B per reference: plane, a, b, c
         parallel_for(hm.n_refs, n_threads, [&](int64_t i_begin, int64_t i_end) {
         for (int64_t i = i_begin; i < i_end; i++) {
             const float *v = hm.pos.data() + (size_t)t.refs[(size_t)i] * 9;
             const f3 a = mk3(v[0], v[1], v[2]), b = mk3(v[3], v[4], v[5]), c = mk3(v[6], v[7], v[8]);
             const f3 N = cross3(b - a, c - a);
-            lp[4 * i] = N.x; lp[4 * i + 1] = N.y; lp[4 * i + 2] = N.z;
-            lp[4 * i + 3] = -dot3(N, a);
-        }
-        });
-        float *lv = reinterpret_cast<float *>(A + L.leaf_verts) + (size_t)hm.ref_base * 12;
-        parallel_for(hm.n_refs, n_threads, [&](int64_t i_begin, int64_t i_end) {
-        for (int64_t i = i_begin; i < i_end; i++) {
-            const float *v = hm.pos.data() + (size_t)t.refs[(size_t)i] * 9;
+            float *rec = lr + 16 * i;
+            rec[0] = N.x; rec[1] = N.y; rec[2] = N.z;
+            rec[3] = -dot3(N, a);
             for (int q = 0; q < 3; q++)
-                for (int c = 0; c < 3; c++) lv[12 * i + 4 * q + c] = v[3 * q + c];
+                for (int k = 0; k < 3; k++) rec[4 + 4 * q + k] = v[3 * q + k];
         }
         });
         // leaf-ordered candidate spheres (no counterpart in the reference; they change no result): a hit the leaf
@@ -474,7 +468,7 @@ bool HostScene::pack(int n_threads, std::string &err) {
 
 // ------------------------------------------------------------------------------------------ export / import
 namespace {
-constexpr uint64_t kBlobMagic = 0x31424f4c4254504dull;  // "MPTBLOB1"
+constexpr uint64_t kBlobMagic = 0x32424f4c4254504dull;  // "MPTBLOB2"
 struct BlobHeader {
     uint64_t magic, struct_bytes, arena_bytes;
     ArenaLayout layout;
@@ -550,8 +544,8 @@ bool import_blob(HostScene &s, const uint8_t *blob, size_t size, std::string &er
     const bool sections_ok =
         fits(L.nodes, (uint64_t)h.total_nodes, sizeof(KdNode)) && fits(L.boxes, (uint64_t)h.total_nodes, 32) &&
         fits(L.tight, (uint64_t)h.total_nodes, 32) && fits(L.tight_pairs, (uint64_t)h.total_nodes / 2 + 1, 64) &&
-        fits(L.refs, (uint64_t)h.total_refs, 4) && fits(L.leaf_planes, (uint64_t)h.total_refs, 16) &&
-        fits(L.leaf_verts, (uint64_t)h.total_refs, 48) && fits(L.leaf_spheres, (uint64_t)h.total_refs / 2 + 4, sizeof(SpherePair)) &&
+        fits(L.refs, (uint64_t)h.total_refs, 4) && fits(L.leaf_recs, (uint64_t)h.total_refs, 64) &&
+        fits(L.leaf_spheres, (uint64_t)h.total_refs / 2 + 4, sizeof(SpherePair)) &&
         fits(L.tri_pos, (uint64_t)h.total_tris, 48) && fits(L.tri_nrm, (uint64_t)h.total_tris, 48) &&
         fits(L.meshes, (uint64_t)h.n_meshes, sizeof(DMesh)) && fits(L.mesh_order, (uint64_t)3 * (uint64_t)h.n_meshes, 4) &&
         fits(L.spheres, (uint64_t)h.n_spheres, 32) && fits(L.planes, (uint64_t)h.n_planes, 32) &&
@@ -639,9 +633,8 @@ DScene HostScene::view(const void *base_v) const {
     d.tight = reinterpret_cast<const f4 *>(base + layout.tight);
     d.tight_pairs = reinterpret_cast<const f4 *>(base + layout.tight_pairs);
     d.refs = reinterpret_cast<const int32_t *>(base + layout.refs);
-    d.leaf_planes = reinterpret_cast<const f4 *>(base + layout.leaf_planes);
+    d.leaf_recs = reinterpret_cast<const f4 *>(base + layout.leaf_recs);
     d.leaf_spheres = reinterpret_cast<const SpherePair *>(base + layout.leaf_spheres);
-    d.leaf_verts = reinterpret_cast<const f4 *>(base + layout.leaf_verts);
     d.tri_pos = reinterpret_cast<const f4 *>(base + layout.tri_pos);
     d.tri_nrm = reinterpret_cast<const f4 *>(base + layout.tri_nrm);
     d.meshes = reinterpret_cast<const DMesh *>(base + layout.meshes);

@@ -30,7 +30,7 @@ struct HostEnv {
 
 // Byte offsets of each section inside the arena (all 256-byte aligned).
 struct ArenaLayout {
-    size_t nodes = 0, boxes = 0, tight = 0, tight_pairs = 0, refs = 0, leaf_planes = 0, leaf_spheres = 0, leaf_verts = 0, tri_pos = 0, tri_nrm = 0, meshes = 0, mesh_order = 0, spheres = 0, planes = 0, lights = 0,
+    size_t nodes = 0, boxes = 0, tight = 0, tight_pairs = 0, refs = 0, leaf_recs = 0, leaf_spheres = 0, tri_pos = 0, tri_nrm = 0, meshes = 0, mesh_order = 0, spheres = 0, planes = 0, lights = 0,
            materials = 0, env = 0, total = 0;
 };
 

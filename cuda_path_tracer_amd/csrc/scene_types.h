@@ -17,8 +17,8 @@
 //                                   leaf scan that found a hit (reference position -> triangle id)
 //   leaf_spheres SpherePair[n_refs/2+4] 32 B per PAIR of references: conservative candidate spheres, streamed by pass 1 of the
 //                                   leaf scan (packed fp32)
-//   leaf_planes float4[n_refs]      plane record (N, -N.a) of each reference, contiguous per leaf: pass 2, marked candidates
-//   leaf_verts  float4[3*n_refs]    the reference's three vertex positions again, in leaf order (no reference -> triangle hop)
+//   leaf_recs   float4[4*n_refs]    64 B per reference, leaf order: plane record (N, -N.a) + the three vertex positions again
+//                                   (no reference -> triangle hop): pass 2, marked candidates -- one line per candidate
 //   tri_pos     float4[3*n_tris]    vertex positions a,b,c (w unused), triangle order: shading (surface_at)
 //   tri_nrm     float4[3*n_tris]    vertex normals, fetched once for the winning triangle
 //   meshes / mesh_order / spheres / planes / lights / materials: small tables; wave-uniform reads go through ldk4() below
@@ -97,11 +97,11 @@ struct DScene {
     const f4 *tight_pairs;  // per sibling pair (left child index >> 1), 64 B: the two cull boxes component-interleaved (48 B) + the two children's nodes (16 B)
                             // (loxL,loxR,hixL,hixR) (loyL,loyR,hiyL,hiyR) (lozL,lozR,hizL,hizR) (pad) for packed fp32
     const int32_t *refs;
-    const f4 *leaf_planes;  // per leaf reference: (N.xyz, -dot(N,a)) of that triangle, in leaf order
+    const f4 *leaf_recs;    // per leaf reference, in leaf order, ONE 64-byte record (half a cache line): (N.xyz, -dot(N,a)) of the
+                            // triangle, then its vertex positions a, b, c -- a marked candidate's plane test and edge tests read
+                            // one line (round 2 kept planes and vertices in two arrays: two to three lines per candidate)
     const SpherePair *leaf_spheres;  // per PAIR of leaf references (global reference index >> 1): spheres that contain
                                      // every hit point the leaf loop could accept for that reference
-    const f4 *leaf_verts;   // per leaf reference: the triangle's vertex positions a,b,c again (3 float4), in leaf order, so the
-                            // exact test of a marked candidate issues all its loads at once (no reference -> triangle hop)
     const f4 *tri_pos;
     const f4 *tri_nrm;
     const DMesh *meshes;

@@ -18,7 +18,7 @@
 //  * The traversal stack lives in LDS (one column per lane, bank-conflict free).
 //  * In a leaf, pass 1 streams conservative candidate spheres (leaf_spheres, packed fp32); only the
 //    marked candidates get the reference's evaluation from leaf-ordered plane and vertex records
-//    (leaf_planes, leaf_verts); the vertex normals are never touched here.
+//    (leaf_recs: one 64-byte record each); the vertex normals are never touched here.
 #pragma once
 #include "scene_types.h"
 
@@ -509,12 +509,13 @@ PT_HD void leaf_scan(const DScene &sc, int first, int count, f3 o, f3 d, const S
             PSTAT(ps, 6);
             const int r = base + (__builtin_ffsll((long long)marked) - 1);
             marked &= marked - 1ull;
-            const f4 pl = sc.leaf_planes[r];
+            const f4 *rec = sc.leaf_recs + 4 * (size_t)r;
+            const f4 pl = rec[0];
             const float t = plane_candidate(pl, o, d, cur, bt);
             if (WORK) wc.planes++;
             if (t > 0.0f) {
                 if (WORK) wc.verts++;
-                const f4 pa = sc.leaf_verts[3 * (size_t)r], pb = sc.leaf_verts[3 * (size_t)r + 1], pc = sc.leaf_verts[3 * (size_t)r + 2];
+                const f4 pa = rec[1], pb = rec[2], pc = rec[3];
                 if (inside_triangle(pl, mk3(pa.x, pa.y, pa.z), mk3(pb.x, pb.y, pb.z), mk3(pc.x, pc.y, pc.z), o, d, t)) {
                     bt = t;
                     bi = r;

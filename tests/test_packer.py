@@ -143,14 +143,15 @@ def test_export_import_round_trip(cube_obj):
         out = blob.copy()
         out[offset:offset + np.dtype(dtype).itemsize] = np.array([value], dtype).view(np.uint8)
         return out
-    for off, val, dt in ((200, 1 << 27, np.int32),      # n_planes
-                         (192, 1 << 30, np.int32),      # n_materials
-                         (176, 1 << 28, np.int64),      # total_nodes
-                         (184, (1 << 31) - 2, np.int64),  # total_refs
-                         (24 + 8 * 13, blob.size, np.uint64),  # layout.planes beyond the arena
-                         (288 + 0, 1 << 40, np.int64),   # mesh 0: n_tris
-                         (288 + 16, 3, np.int64),        # mesh 0: node_base
-                         (288 + 80 + 32, 1 << 33, np.int64)):  # mesh 1: n_nodes
+    # header: magic, struct_bytes, arena_bytes (24 B); 17 section offsets (136 B); 3 totals (24 B); 9 int32; camera; time = 280 B
+    for off, val, dt in ((192, 1 << 27, np.int32),      # n_planes
+                         (184, 1 << 30, np.int32),      # n_materials
+                         (168, 1 << 28, np.int64),      # total_nodes
+                         (176, (1 << 31) - 2, np.int64),  # total_refs
+                         (24 + 8 * 12, blob.size, np.uint64),  # layout.planes beyond the arena
+                         (280 + 0, 1 << 40, np.int64),   # mesh 0: n_tris
+                         (280 + 16, 3, np.int64),        # mesh 0: node_base
+                         (280 + 80 + 32, 1 << 33, np.int64)):  # mesh 1: n_nodes
         with pytest.raises(_lib.MiptError, match="blob"):
             Scene().import_blob(patched(off, val, dt))
 
