@@ -36,7 +36,14 @@ PT_HD f3 norm3(f3 a) { return a * (1 / (len3(a) + kEps)); }
 // ONE rounding per component, i.e. the fused multiply-add nvcc's default (-fmad=true) makes of a product that feeds a
 // sum.  This is the one contraction of the reference's build that its published pictures show (deviation 7):
 // it decides how often a hit on a min-X box face passes `minX <= position.x` (Q5, no epsilon).  Nothing else is fused.
+// (A FITTED model: chosen because it matches the reference's two published renders, which cannot tell it from a build with
+//  every multiply-add contracted -- tests/test_pin_mutations.py.  -DMIPT_RAY_AT_UNFUSED builds the library with the source
+//  text's two roundings instead, the oracle's switch "dev7_unfused" is its twin, should a reference-side vector ever decide.)
+#ifdef MIPT_RAY_AT_UNFUSED
+PT_HD float fma_at(float o, float d, float t) { return o + d * t; }
+#else
 PT_HD float fma_at(float o, float d, float t) { return __builtin_fmaf(d, t, o); }
+#endif
 PT_HD f3 ray_at(f3 o, f3 d, float t) { return mk3(fma_at(o.x, d.x, t), fma_at(o.y, d.y, t), fma_at(o.z, d.z, t)); }
 PT_HD float avg3(f3 a) { return (a.x + a.y + a.z) / 3.0f; }
 

@@ -296,6 +296,8 @@ PT_HD bool descend_fast(const DScene &sc, f3 o, f3 d, SlabBox &cur, int &node, K
         const f4 tbx = tb[0], tby = tb[1], tbz = tb[2], tbn = tb[3];
         KdNodePair pair;
         pair.l.a = as_u32(tbn.x); pair.l.b = as_u32(tbn.y); pair.r.a = as_u32(tbn.z); pair.r.b = as_u32(tbn.w);
+        // (Touching the step records of BOTH children one step ahead -- a dummy load each, consumed only at the end of the
+        //  walk -- was measured: coherent closest hit 3690 -> 3390 Mrays/s, incoherent 2240 -> 1885, 1080p frame -8 %.)
         bool cull_l, cull_r;
         float near_l, near_r;
         pair_culled(tbx, tby, tbz, o, d, cull_l, cull_r, near_l, near_r);
