@@ -552,7 +552,7 @@ def main():
             "shade_share_of_gpu_time": round(tot["ms_shade"] / max(1e-9, tot["ms_total"]), 3),
             "image_mean": round(img_mean, 6), "nonfinite_samples": tot["nonfinite_samples"],
             "scene_seconds": round(t_build, 3), "commit_s": round(t_build, 3),
-            "commit_note": "kd build + pack + upload of the C2 scene (81,920 triangles: built and packed on the host, below the GPU builders' threshold); the large meshes' commit times are in closest_hit.commit_s and other_configs[].commit_s",
+            "commit_note": "kd build + pack + upload of the C2 scene (81,920 triangles; rank 0 builds and packs it on the HOST so that the packed arena can be broadcast to the other ranks, then every rank uploads it; includes the first HIP call of the process); commits that build and pack on the GPU are in closest_hit.commit_s and other_configs[].commit_s",
             "roofline": roofline_views(pmc.get("c2") if pmc else None, tot["ms_extend"] / launches, tot["rays_extended"] / launches,
                                        alg_bpr, ref_bpr,
                                        {"launches": tot["extend_launches"], "pmc_source": pmc_source,

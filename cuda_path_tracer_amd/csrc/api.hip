@@ -441,7 +441,7 @@ int mipt_trace_closest_device(mipt_scene *s, int slot, const float *d_ray_o, con
         if (count) fill_counters(dc, st);
         if (mode == kCountWork) fill_work_counters(dc, st);
     }
-#ifdef MIPT_PHASE_STATS
+#if defined(MIPT_PHASE_STATS) || defined(MIPT_PHASE_CLOCKS)
     if (!count) dump_phase_stats(dc, "trace_closest");
 #endif
     return 0;

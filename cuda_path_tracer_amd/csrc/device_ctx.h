@@ -104,7 +104,21 @@ struct DeviceCtx {
     EventPool events;
 };
 
-#ifdef MIPT_PHASE_STATS
+#ifdef MIPT_PHASE_CLOCKS
+// developer build: shader clocks the waves of the extend kernel spent per section of the persistent loop (kernels_extend.h)
+inline void dump_phase_stats(DeviceCtx &dc, const char *what) {
+    static const char *names[6] = {"finish (store result)", "refill (fetch rays)", "open mesh (root slab)", "leaf scan (pooled)",
+                                   "pop (rebuild slab)", "descend (<= step_cap steps)"};
+    unsigned long long v[6];
+    (void)hipMemcpy(v, dc.counters.as<char>() + 128, sizeof(v), hipMemcpyDeviceToHost);
+    (void)hipMemset(dc.counters.as<char>() + 128, 0, sizeof(v));
+    double total = 0;
+    for (int i = 0; i < 6; i++) total += (double)v[i];
+    fprintf(stderr, "[phase clocks] %s\n", what);
+    for (int i = 0; i < 6; i++)
+        fprintf(stderr, "  %-28s wave-clocks %16llu  share %.3f\n", names[i], v[i], total > 0 ? (double)v[i] / total : 0.0);
+}
+#elif defined(MIPT_PHASE_STATS)
 // developer build: print and clear the phase table the instrumented extend kernel accumulated (see traverse.h)
 inline void dump_phase_stats(DeviceCtx &dc, const char *what) {
     static const char *names[12] = {"loop", "finish", "refill", "open_mesh", "scan_entry", "scan_group4", "edge_tests", "pop_iter",

@@ -27,7 +27,15 @@ struct LdsStack {
     int *col;  // &stack[threadIdx.x]
     __device__ __forceinline__ void push(int sp, int v) { col[sp * kExtendBlock] = v; }
     __device__ __forceinline__ int pop(int sp) { return col[sp * kExtendBlock]; }
+#if 1
+    // Rows above the stack: per-ray values that are written when the ray is fetched and read when it is finished (the sphere /
+    // plane answer it arrived with, the best mesh triangle so far).  In registers they were what the compiler spilled to
+    // scratch MEMORY -- and every `s_waitcnt vmcnt(0)` behind such a spill store waits for its acknowledgement.
+    __device__ __forceinline__ void cold_set(int k, int v) { col[(kStackDepth + k) * kExtendBlock] = v; }
+    __device__ __forceinline__ int cold_get(int k) const { return col[(kStackDepth + k) * kExtendBlock]; }
+#endif
 };
+constexpr int kColdRows = 3;  // q_t, q_prim, prim
 
 __device__ __forceinline__ unsigned int wave_sum(unsigned int v) {
 #pragma unroll
@@ -233,7 +241,7 @@ __global__ __launch_bounds__(kExtendBlock, 5) void k_extend(DScene sc, const f4 
         }
     }
     constexpr bool WORK = MODE == kCountWork;
-    __shared__ int stack_mem[kStackDepth * kExtendBlock];
+    __shared__ int stack_mem[(kStackDepth + kColdRows) * kExtendBlock];
     __shared__ int coop_items[(kExtendBlock / 64) * 2 * kCoopItems];
     __shared__ unsigned long long coop_res[kExtendBlock];
     LdsStack stk{stack_mem + threadIdx.x};
@@ -251,6 +259,21 @@ __global__ __launch_bounds__(kExtendBlock, 5) void k_extend(DScene sc, const f4 
 #ifdef MIPT_PHASE_STATS
     PhaseStats ps = {};
 #endif
+    // developer build (-DMIPT_PHASE_CLOCKS, scripts/build_phase_stats.sh): shader clocks of every wave per section of the loop
+#ifdef MIPT_PHASE_CLOCKS
+    // (32-bit, forced into scalar registers: as vector values the compiler spilled them to scratch memory, and every reload
+    //  waited for ALL outstanding vector memory operations -- the result store of the finish section among them, 8-13 k clocks)
+    uint32_t pclk0 = 0u, pclk1 = 0u, pclk2 = 0u, pclk3 = 0u, pclk4 = 0u, pclk5 = 0u;
+    uint32_t pclk_t = __builtin_amdgcn_readfirstlane((uint32_t)__builtin_readcyclecounter());
+#define PCLK(i)                                                                                            \
+    do {                                                                                                   \
+        const uint32_t now_ = __builtin_amdgcn_readfirstlane((uint32_t)__builtin_readcyclecounter());      \
+        pclk##i = __builtin_amdgcn_readfirstlane(pclk##i + (now_ - pclk_t));                               \
+        pclk_t = now_;                                                                                     \
+    } while (0)
+#else
+#define PCLK(i)
+#endif
 
     bool has_ray = false, exhausted = false;
     bool start_mesh = false;  // lane must open mesh `m`, or store its result when m == n_meshes
@@ -263,8 +286,34 @@ __global__ __launch_bounds__(kExtendBlock, 5) void k_extend(DScene sc, const f4 
     const bool prune_meshes = !COUNT && sc.n_meshes > 1;  // wave-uniform
     uint32_t slot = 0u;
     int m = 0, node = 0, sp = 0;
-    int prim = -1, q_prim = -1;      // best mesh triangle / best sphere-or-plane
-    float best = -1.0f, q_t = -1.0f;
+#ifndef MIPT_COLD_MASK
+#define MIPT_COLD_MASK 7
+#endif
+#if (MIPT_COLD_MASK & 1)
+#define COLD_QT() as_f32((uint32_t)stk.cold_get(0))
+#define COLD_SET_QT(t_) stk.cold_set(0, (int)as_u32(t_))
+#else
+    float q_t = -1.0f;
+#define COLD_QT() q_t
+#define COLD_SET_QT(t_) q_t = (t_)
+#endif
+#if (MIPT_COLD_MASK & 2)
+#define COLD_QPRIM() stk.cold_get(1)
+#define COLD_SET_QPRIM(p_) stk.cold_set(1, (p_))
+#else
+    int q_prim = -1;
+#define COLD_QPRIM() q_prim
+#define COLD_SET_QPRIM(p_) q_prim = (p_)
+#endif
+#if (MIPT_COLD_MASK & 4)
+#define COLD_PRIM() stk.cold_get(2)
+#define COLD_SET_PRIM(p_) stk.cold_set(2, (p_))
+#else
+    int prim = -1;
+#define COLD_PRIM() prim
+#define COLD_SET_PRIM(p_) prim = (p_)
+#endif
+    float best = -1.0f;
     KdNode nd = {0u, kLeafTag};      // the 8 bytes of `node`
     f3 o = mk3(0.f, 0.f, 0.f), d = mk3(0.f, 0.f, 1.f);
     SlabBox cur;  // fast path: a masked slab (see descend_fast)
@@ -274,14 +323,19 @@ __global__ __launch_bounds__(kExtendBlock, 5) void k_extend(DScene sc, const f4 
     // what follows a leaf visit: bt > 0 = accepted hit at triangle bi (mesh.cuh:300 ends this mesh; kernel.cu:149
     // keeps the earlier mesh on ties), else continue with the stacked far child, else the mesh is exhausted
     const float inf = __builtin_inff();
-    auto closest_so_far = [&]() { return fmin_raw(best > 0.0f ? best : inf, q_t > 0.0f ? q_t : inf); };
+    auto closest_so_far = [&]() {
+        const float qt = COLD_QT();
+        return fmin_raw(best > 0.0f ? best : inf, qt > 0.0f ? qt : inf);
+    };
     auto after_leaf = [&](float bt, int bi) {
         if (prune_meshes && bt > 0.0f && (slot & kTaintBit) != 0u && bt <= closest_so_far()) {
             slot |= kNoPruneBit;  // the hit would be used, but the reference may have stopped in a subtree that was dropped
             start_mesh = true;
         } else if (bt > 0.0f) {
             // (equal hits: the lower triangle id is the earlier mesh -- the production kernel opens meshes out of order)
-            if (best < 0.0f || bt < best || (bt == best && bi < prim)) { best = bt; prim = bi; }
+            bool take = best < 0.0f || bt < best;
+            if (!take && bt == best) take = bi < COLD_PRIM();
+            if (take) { best = bt; COLD_SET_PRIM(bi); }
             m++;
             start_mesh = true;
             slot &= ~kNoPruneBit;
@@ -300,15 +354,17 @@ __global__ __launch_bounds__(kExtendBlock, 5) void k_extend(DScene sc, const f4 
         if (has_ray && start_mesh && m >= sc.n_meshes) {
             // spheres/planes were evaluated when the ray was made; a mesh hit wins ties because meshes come first
             PSTAT(ps, 1);
-            const bool mesh_wins = (best > 0.0f) && (q_t < 0.0f || best <= q_t);
+            const float qt = COLD_QT();
+            const bool mesh_wins = (best > 0.0f) && (qt < 0.0f || best <= qt);
             HitRec h;
-            h.t = mesh_wins ? best : q_t;
-            h.prim = mesh_wins ? prim : q_prim;
+            h.t = mesh_wins ? best : qt;
+            h.prim = mesh_wins ? COLD_PRIM() : COLD_QPRIM();
             hits[slot & kSlotMask] = h;
             if (COUNT) hit_tris += mesh_wins ? 1u : 0u;
             has_ray = false;
             start_mesh = false;
         }
+        PCLK(0);
         // ---- refill idle lanes from the global work counter --------------------------------------------
         const unsigned long long idle = __ballot(!has_ray);
         if (idle != 0ull && !exhausted) {
@@ -338,11 +394,11 @@ __global__ __launch_bounds__(kExtendBlock, 5) void k_extend(DScene sc, const f4 
                     }
                     d = mk3(d4.x, d4.y, d4.z);
                     best = -1.0f;
-                    prim = -1;
+                    COLD_SET_PRIM(-1);
                     {  // the sphere / plane answer parked in the hit slot by the stage that made the ray (kernel.cu:151-158)
                         const HitRec q = hits[slot];
-                        q_t = q.t;
-                        q_prim = q.prim;
+                        COLD_SET_QT(q.t);
+                        COLD_SET_QPRIM(q.prim);
                     }
                     m = 0;
                     start_mesh = true;
@@ -357,6 +413,7 @@ __global__ __launch_bounds__(kExtendBlock, 5) void k_extend(DScene sc, const f4 
                 }
             }
         }
+        PCLK(1);
         if (__ballot(has_ray) == 0ull) {
             if (exhausted) break;
             continue;
@@ -408,6 +465,7 @@ __global__ __launch_bounds__(kExtendBlock, 5) void k_extend(DScene sc, const f4 
                 m++;  // the ray misses this mesh's root box
             }
         }
+        PCLK(2);
         // ---- postponed leaf scans: run the candidate loop only when enough lanes wait for one -------------------
         // (about 9 of 10 leaf visits are culled; scanning the rest one by one would run the loop at ~10% lane use)
         {
@@ -424,6 +482,7 @@ __global__ __launch_bounds__(kExtendBlock, 5) void k_extend(DScene sc, const f4 
                 }
             }
         }
+        PCLK(3);
         // ---- continue with the far child that was stacked (mesh.cuh:263): its box is re-read --------------------
         if (COUNT) {
             if (need_pop) {
@@ -447,6 +506,7 @@ __global__ __launch_bounds__(kExtendBlock, 5) void k_extend(DScene sc, const f4 
             if (WORK) wc.pops++;
             if ((nd.b >> 30) == 3u) pending = true;
         }
+        PCLK(4);
         if (!has_ray || pending || start_mesh) continue;
 
         // ---- walk down (at most step_cap steps per round), then the leaf visit ---------------------------------
@@ -468,9 +528,16 @@ __global__ __launch_bounds__(kExtendBlock, 5) void k_extend(DScene sc, const f4 
             if (dead_end) after_leaf(-1.0f, -1);                 // same continuation as a fruitless leaf visit
             else if ((nd.b >> 30) == 3u) pending = true;        // a leaf that passed its cull test: scanned in a batch
         }
+        PCLK(5);
     }
     if (COUNT) flush_counters(tc, hit_tris, ctr);
     if (WORK) flush_work_counters(wc, ctr + kCtrWork / 8);
+#ifdef MIPT_PHASE_CLOCKS
+    if (!COUNT && lane == 0) {
+        const uint32_t pc[6] = {pclk0, pclk1, pclk2, pclk3, pclk4, pclk5};
+        for (int i = 0; i < 6; i++) atomicAdd(&ctr[16 + i], (unsigned long long)pc[i]);
+    }
+#endif
 #ifdef MIPT_PHASE_STATS
     if (!COUNT) {  // ctr + 16: kCtrPhase (device_ctx.h)
         for (int i = 0; i < kPhases; i++) {

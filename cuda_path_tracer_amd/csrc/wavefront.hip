@@ -900,7 +900,7 @@ int wavefront_render(const HostScene &hs, DeviceCtx &dc, const mipt_render_confi
     }
     WF_TRY(hipEventRecord(ev_end, sm));
     WF_TRY(hipStreamSynchronize(sm));
-#ifdef MIPT_PHASE_STATS
+#if defined(MIPT_PHASE_STATS) || defined(MIPT_PHASE_CLOCKS)
     if (!count_mode) dump_phase_stats(dc, "render");
 #endif
     if (getenv("MIPT_TIMING")) {  // queue lengths of the last pass and the duration of every extend launch, in launch order

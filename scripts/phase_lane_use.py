@@ -1,7 +1,8 @@
 """Lane use per phase of the persistent closest-hit kernel (developer build variants/libmipt_stats.so, made by
 scripts/build_phase_stats.sh; the library prints one table per call on stderr) for one C2 bench step and the two
 closest-hit batches, plus the refill rate per cursor word (one word took 72 M atomics/s of a ~88 M/s
-cap; now 8 words).  usage: python scripts/phase_lane_use.py  2>&1 | tee profiles/r2_phase_lane_use.txt"""
+cap; now 8 words).  usage: python scripts/phase_lane_use.py  2>&1 | tee profiles/r3_phase_lane_use.txt
+(-DMIPT_PHASE_CLOCKS build, variants/libmipt_clocks.so: the same runs print the shader clocks per section of the loop instead)"""
 import os
 import sys
 
@@ -9,7 +10,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from cuda_path_tracer_amd import _lib  # noqa: E402
 
-_lib.LIB_PATH = os.path.join(ROOT, "variants", "libmipt_stats.so")
+_lib.LIB_PATH = os.environ.get("MIPT_LIB") or os.path.join(ROOT, "variants", "libmipt_stats.so")  # MIPT_LIB=variants/libmipt_clocks.so: clocks per section
 from cuda_path_tracer_amd import generators as G  # noqa: E402
 from cuda_path_tracer_amd.scene import Scene, make_config  # noqa: E402
 
