@@ -197,6 +197,8 @@ __device__ __forceinline__ void leaf_scan_coop(const DScene &sc, bool pending, i
                     if (WORK) wc.planes++;
                     if (t > 0.0f) {
                         if (WORK) wc.verts++;
+                        // (loading the whole 64-byte record before the plane test -- one round trip instead of two -- measured:
+                        //  coherent closest hit -2 %, the rest unchanged; 42 % of the marked candidates fail the plane test)
                         const f4 pa = rec[1], pb = rec[2], pc = rec[3];
                         if (inside_triangle(pl, mk3(pa.x, pa.y, pa.z), mk3(pb.x, pb.y, pb.z), mk3(pc.x, pc.y, pc.z), fo, fd, t))
                             atomicMin(&res[p], ((unsigned long long)as_u32(t) << 32) | (unsigned long long)(unsigned int)r);
@@ -213,7 +215,13 @@ __device__ __forceinline__ void leaf_scan_coop(const DScene &sc, bool pending, i
     bi = -1;
     if (pending && best_key != ~0ull) {
         bt = as_f32((uint32_t)(best_key >> 32));
+#ifdef MIPT_TRI_FROM_REFS
         bi = sc.refs[(int)(uint32_t)best_key];  // reference position -> triangle id, once per leaf
+#else
+        // reference position -> triangle id, once per leaf: it rides in a.w of the leaf record, a line the winning test has
+        // just touched (`refs` is a cold array: this load used to go to HBM)
+        bi = (int)as_u32(sc.leaf_recs[4 * (size_t)(uint32_t)best_key + 1].w);
+#endif
     }
 }
 

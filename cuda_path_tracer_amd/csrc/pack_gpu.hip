@@ -154,6 +154,7 @@ __global__ __launch_bounds__(kPackBlock) void k_pack_refs(MeshArgs m, ArenaPtrs 
             for (int c = 0; c < 3; c++) rec[4 + 4 * q + c] = v[3 * q + c];
             rec[4 + 4 * q + 3] = 0.0f;
         }
+        rec[7] = __int_as_float(tri + (int32_t)m.tri_base);  // a.w: the global triangle id (scene.cpp)
     }
     // candidate sphere (scene.cpp: the smaller of the triangle's smallest enclosing sphere and the sphere around
     // AABB(triangle) within the leaf's cull box, grown by its margin) -- the host's double arithmetic, operation for operation

@@ -287,6 +287,12 @@ bool HostScene::pack(int n_threads, std::string &err) {
             rec[3] = -dot3(N, a);
             for (int q = 0; q < 3; q++)
                 for (int k = 0; k < 3; k++) rec[4 + 4 * q + k] = v[3 * q + k];
+            // a.w: the GLOBAL triangle id (int bits) -- the winner of a leaf scan reads it from the line its test just touched
+            // instead of from `refs`, a cold array (b.w, c.w stay 0)
+            const int32_t gtri = t.refs[(size_t)i] + (int32_t)hm.tri_base;
+            memcpy(rec + 7, &gtri, 4);
+            rec[11] = 0.0f;
+            rec[15] = 0.0f;
         }
         });
         // leaf-ordered candidate spheres (no counterpart in the reference; they change no result): a hit the leaf

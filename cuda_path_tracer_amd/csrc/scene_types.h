@@ -18,6 +18,7 @@
 //   leaf_spheres SpherePair[n_refs/2+4] 32 B per PAIR of references: conservative candidate spheres, streamed by pass 1 of the
 //                                   leaf scan (packed fp32)
 //   leaf_recs   float4[4*n_refs]    64 B per reference, leaf order: plane record (N, -N.a) + the three vertex positions again
+//                                   (a.w = the global triangle id as int bits, b.w = c.w = 0)
 //                                   (no reference -> triangle hop): pass 2, marked candidates -- one line per candidate
 //   tri_pos     float4[3*n_tris]    vertex positions a,b,c (w unused), triangle order: shading (surface_at)
 //   tri_nrm     float4[3*n_tris]    vertex normals, fetched once for the winning triangle

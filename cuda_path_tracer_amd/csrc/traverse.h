@@ -525,7 +525,7 @@ PT_HD void leaf_scan(const DScene &sc, int first, int count, f3 o, f3 d, const S
             }
         }
     }
-    if (bi >= 0) bi = sc.refs[bi];  // reference position -> triangle id, once per leaf
+    if (bi >= 0) bi = (int)as_u32(sc.leaf_recs[4 * (size_t)bi + 1].w);  // reference position -> triangle id, once per leaf (rides in a.w)
 }
 
 // Mesh::intersect (mesh.cuh:253-305), one ray start to finish.  Stack: push(sp, v) / pop(sp) on a per-lane column.
