@@ -510,6 +510,21 @@ __global__ __launch_bounds__(kExtendBlock, 5) void k_extend(DScene sc, const f4 
                                   //  `nodes` fewer per pop -- measured no gain on the incoherent batch and -0.6 % on the 1080p frame)
             load_slab(sc, node, o, d, cur);
             mask_slab(cur, o, d);
+#ifdef MIPT_POP_TWICE
+            {   // sensitivity probe (developer build): the pop's slab arithmetic executed a second time, same results.  What the
+                // kernel slows down by is the share of its time this arithmetic takes -- the ceiling of what pooling it could save.
+                f3 o2 = o;
+                asm volatile("" : "+v"(o2.x), "+v"(o2.y), "+v"(o2.z));
+                SlabBox c2;
+                load_slab(sc, node, o2, d, c2);
+                mask_slab(c2, o2, d);
+#pragma unroll
+                for (int k = 0; k < 3; k++) {
+                    cur.tlo[k] = fmin_raw(cur.tlo[k], c2.tlo[k]);
+                    cur.thi[k] = fmin_raw(cur.thi[k], c2.thi[k]);
+                }
+            }
+#endif
             need_pop = false;
             if (WORK) wc.pops++;
             if ((nd.b >> 30) == 3u) pending = true;
