@@ -8,10 +8,11 @@
 //   k_keys     one lane per (node, triangle) reference: the triangle's two membership keys for this node (smallest
 //              admissible coordinate for the left child, largest for the right child -- see kd_build.cpp's header) and its
 //              up-to-three split candidates (vertex coordinates strictly inside the node on the split axis, else +inf)
-//   rocPRIM    ONE device-wide radix sort of the level's candidates as 64-bit keys (node slot << 32 | order-preserving
+//   kd_sort.h  ONE device-wide radix sort of the level's candidates as 64-bit keys (node slot << 32 | order-preserving
 //              bits of the coordinate): every node's candidates end up contiguous and ascending (mesh.cu:68 sorts them per
 //              node) however the references are spread over the nodes -- a segmented sort gives a 4 M-key root segment to
-//              one workgroup (measured: 89 % of the build)
+//              one workgroup (measured with the library's: 89 % of the build).  The library's radix_sort_keys until round 3;
+//              now the build's own LSD sort (8-bit digits, ballot match-any ranking)
 //   k_search   one workgroup per node: the median walk -- each of its <= 21 counting passes is a block-wide reduction
 //              over the node's keys -- then the final plane and the sizes of the two children
 //   (host)     256 bytes per node come back; the host decides which children are leaves (<= 50 triangles or depth > 15)
@@ -22,7 +23,6 @@
 // by tests/test_gpu_kd_build.py on 1.3 M triangles).  The flat numbering (children adjacent, depth-first) is applied by
 // the same host routine as for the host build (assemble_kd_tree).
 #include <hip/hip_runtime.h>
-#include <rocprim/device/device_radix_sort.hpp>
 
 #include <algorithm>
 #include <chrono>
@@ -31,6 +31,7 @@
 #include <vector>
 
 #include "kd_build.h"
+#include "kd_sort.h"
 
 namespace mipt {
 namespace {
@@ -327,18 +328,17 @@ bool build_kd_tree_gpu(int device, const float *pos, int64_t n_tris, KdTree &out
         hipLaunchKernelGGL(k_keys, dim3((unsigned)((n_refs + kBuildBlock - 1) / kBuildBlock)), dim3(kBuildBlock), 0, st,
                            pos_dev, d_nodes.as<LevelNode>(), d_tris[cur].as<int>(), d_owner[cur].as<int>(), n_refs,
                            d_kl.as<float>(), d_kr.as<float>(), d_cand.as<unsigned long long>());
+        const unsigned long long *cand_sorted;
         {
             int owner_bits = 1;
             while ((1 << owner_bits) < n_nodes) owner_bits++;
-            size_t temp_bytes = 0;
-            KD_TRY(rocprim::radix_sort_keys(nullptr, temp_bytes, d_cand.as<unsigned long long>(), d_cand_sorted.as<unsigned long long>(),
-                                            3 * (size_t)n_refs, 0, 32 + owner_bits, st));
-            KD_TRY(d_temp.reserve(temp_bytes));
-            KD_TRY(rocprim::radix_sort_keys(d_temp.p, temp_bytes, d_cand.as<unsigned long long>(), d_cand_sorted.as<unsigned long long>(),
-                                            3 * (size_t)n_refs, 0, 32 + owner_bits, st));
+            KD_TRY(d_temp.reserve(kd_sort_scratch_bytes(3 * (int64_t)n_refs)));
+            cand_sorted = launch_kd_sort(st, d_cand.as<unsigned long long>(), d_cand_sorted.as<unsigned long long>(), 3 * (int64_t)n_refs,
+                                         32 + owner_bits, d_temp.p);
+            KD_TRY(hipGetLastError());
         }
         hipLaunchKernelGGL(k_search, dim3((unsigned)n_nodes), dim3(kBuildBlock), 0, st, d_nodes.as<LevelNode>(), d_kl.as<float>(),
-                           d_kr.as<float>(), d_cand_sorted.as<unsigned long long>(), d_res.as<SplitResult>());
+                           d_kr.as<float>(), cand_sorted, d_res.as<SplitResult>());
         h_res.resize((size_t)n_nodes);
         KD_TRY(hipMemcpyAsync(h_res.data(), d_res.p, (size_t)n_nodes * sizeof(SplitResult), hipMemcpyDeviceToHost, st));
         KD_TRY(hipStreamSynchronize(st));
