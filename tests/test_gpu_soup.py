@@ -70,6 +70,13 @@ def test_triangle_soups(kind, n, monkeypatch):
     _walk(h.kd_export(0), 0, wh)
     _walk(o.kd_export(0), 0, wo)
     assert ws == wo and wh == wo, kind
+    # ... and the arena the GPU packer made of it (leaf records, cull boxes, step records, candidate spheres in double) is the
+    # host packer's, byte for byte, on this geometry too (degenerate boxes, slivers, hundreds of coincident triangles)
+    assert s.packed_on_gpu() == (n >= 16384) and not h.packed_on_gpu()
+    nb = s.device_bytes()
+    assert nb == h.device_bytes()
+    a, b = s.export_blob()[-nb:], h.export_blob()[-nb:]
+    assert np.array_equal(a, b), "%s: %d arena bytes differ, first at %d" % (kind, int((a != b).sum()), int(np.flatnonzero(a != b)[0]))
     ro, rd = G.incoherent_rays(1 << 15, (-3, -3.5, -4.5), (3, 1.5, 0.5))
     co, cd = G.camera_rays(desc.camera, 128, 128)
     ro, rd = np.concatenate([ro, co]), np.concatenate([rd, cd])
