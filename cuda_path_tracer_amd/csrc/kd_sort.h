@@ -1,5 +1,5 @@
 // kd_sort.h -- the device-wide key sort of the GPU kd build (kd_build_gpu.hip): 64-bit keys (node slot << 32 | order-
-// preserving bits of a coordinate), ascending on their low `key_bits` bits.  Rounds 2-3 called rocPRIM's radix_sort_keys here.
+// preserving bits of a coordinate), ascending on their low `key_bits` bits.  Round 2 called rocPRIM's radix_sort_keys here.
 //
 // A least-significant-digit radix sort, 8 bits per pass, three launches per pass, wave64 throughout:
 //   k_kdsort_hist     every block counts the digits of its tile (4096 keys) in LDS and writes them digit-major:

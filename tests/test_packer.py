@@ -187,3 +187,14 @@ def test_product_does_not_reference_the_oracle():
                 text = open(os.path.join(dirpath, f), errors="replace").read()
                 assert "liboracle" not in text and "oracle/" not in text and "import oracle" not in text \
                     and "from oracle" not in text, os.path.join(dirpath, f)
+
+
+def test_product_holds_no_library_kernels():
+    """Queue binning, the kd build's key sort, scans and compactions are the package's own wave64 kernels: nothing under
+    csrc/ includes rocPRIM, hipCUB, rocThrust or Thrust."""
+    csrc = os.path.join(ROOT, "cuda_path_tracer_amd", "csrc")
+    for f in os.listdir(csrc):
+        if f.endswith((".h", ".cpp", ".hip")):
+            text = open(os.path.join(csrc, f), errors="replace").read()
+            for inc in re.findall(r"#include\s*[<\"]([^>\"]+)[>\"]", text):
+                assert not any(lib in inc.lower() for lib in ("rocprim", "hipcub", "thrust", "cub/")), (f, inc)
