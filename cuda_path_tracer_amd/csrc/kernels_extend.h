@@ -232,7 +232,10 @@ __device__ __forceinline__ void leaf_scan_coop(const DScene &sc, bool pending, i
 // tune.common_origin != 0: every ray of the launch starts at the eye (1: primary rays) or at lights[0] (2: direct-
 // connection shadow rays); ray_o is not read -- the stage that made the rays does not write 16 bytes per ray either.
 template <int MODE>
-__global__ __launch_bounds__(kExtendBlock, 5) void k_extend(DScene sc, const f4 *__restrict__ ray_o,
+#ifndef MIPT_EXTEND_WAVES
+#define MIPT_EXTEND_WAVES 5  // waves per SIMD the register budget is cut for (5: 96 VGPRs; 4: 128 -- measured slower)
+#endif
+__global__ __launch_bounds__(kExtendBlock, MIPT_EXTEND_WAVES) void k_extend(DScene sc, const f4 *__restrict__ ray_o,
                                                          const f4 *__restrict__ ray_d, const int *__restrict__ queue,
                                                          const int *__restrict__ count_ptr, int n_fixed,
                                                          HitRec *__restrict__ hits, int *__restrict__ work,
