@@ -238,6 +238,9 @@ def other_config(name, G, cube):
     if name == "C4":
         return (G.scene_env_sphere(8, env_f32=env_faces_1024(G)), dict(width=3840, height=2160, spp=16, cam_depth=6, light_depth=0, use_envmap=True),
                 "env map + icosphere L8 (1,310,720 tris), simple d6, 4K, 16 of 1024 spp")
+    if name == "C4L":  # not a BASELINE config: C4 with the cube map ALSO sampled as a light (use_envmap == 2, build-defined)
+        return (G.scene_env_sphere(8, env_f32=env_faces_1024(G)), dict(width=3840, height=2160, spp=16, cam_depth=6, light_depth=0, use_envmap=2),
+                "C4 with the env map sampled as a light (use_envmap = 2), 16 spp")
     if name == "C5":
         return (G.scene_multi_sphere(8), dict(width=3840, height=2160, spp=4, cam_depth=5, light_depth=5),
                 "8 x icosphere L8 (10,485,760 tris), bidirectional 5+5, 4K, 4 of 4096 spp")

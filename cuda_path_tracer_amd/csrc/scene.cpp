@@ -7,6 +7,7 @@
 //   copyToDevice call sites    copyToDevice/copyToDevice.h:8-55 -> ONE arena, uploaded by api.hip
 #include "scene_host.h"
 #include "pack_gpu.h"
+#include "shade.h"
 
 #include <algorithm>
 #include <atomic>
@@ -32,6 +33,63 @@ static void parallel_for(int64_t n, int n_threads, F &&body) {
         th.emplace_back([&body, b, e] { body(b, e); });
     }
     for (auto &x : th) x.join();
+}
+
+// ------------------------------------------------------------------------------------------ cube map as a light
+// Sampling tables of the cube map (use_envmap == 2; shade.h env_light_sample reads them): weight of a texel = average(rgb) x
+// solid angle, summed in double in index order, stored as float CDFs whose last entry is 1.  marg has one entry more than
+// rows: 1.0f when the map can be sampled, 0.0f when it is black (or absent).  NaN, negative and infinite texels get no
+// probability.  Rows are independent: they are spread over the builder's threads, the result does not depend on how.
+static void build_env_light(const HostEnv &env, float *marg, float *cond, int n_threads) {
+    const int w = env.w, h = env.h;
+    const size_t rows = (size_t)6 * h;
+    std::vector<double> row_sum(rows, 0.0);
+    DScene texels;  // just enough of a view for env_texel()
+    memset(&texels, 0, sizeof(texels));
+    if (env.rgbe.empty()) texels.env_f32 = env.f32.data();
+    else texels.env_rgbe = env.rgbe.data();
+    auto do_rows = [&](size_t r_begin, size_t r_end) {
+        std::vector<double> acc((size_t)w);
+        for (size_t R = r_begin; R < r_end; R++) {
+            const int face = (int)(R / h), row = (int)(R % h);
+            double run = 0.0;
+            for (int c = 0; c < w; c++) {
+                f3 dir;
+                float sa;
+                env_texel_geometry(face, row, c, w, h, dir, sa);
+                const f3 px = env_texel(texels, (size_t)face * w * h + (size_t)row * w + c);
+                const double lum = ((double)px.x + (double)px.y + (double)px.z) / 3.0;
+                run += (lum > 0.0 && lum < (double)INFINITY) ? lum * (double)sa : 0.0;
+                acc[(size_t)c] = run;
+            }
+            row_sum[R] = run;
+            float *cr = cond + R * w;
+            for (int c = 0; c < w; c++) cr[c] = 1.0f;
+            if (run > 0.0)
+                for (int c = 0; c + 1 < w; c++) cr[c] = (float)(acc[(size_t)c] / run);
+        }
+    };
+    const size_t nt = std::max<size_t>(1, std::min<size_t>((size_t)std::max(1, n_threads), rows / 64));
+    if (nt <= 1) {
+        do_rows(0, rows);
+    } else {
+        std::vector<std::thread> th;
+        const size_t chunk = (rows + nt - 1) / nt;
+        for (size_t k = 0; k < nt; k++) {
+            const size_t b = k * chunk, e = std::min(rows, b + chunk);
+            if (b < e) th.emplace_back([&do_rows, b, e] { do_rows(b, e); });
+        }
+        for (auto &x : th) x.join();
+    }
+    for (size_t R = 0; R <= rows; R++) marg[R] = 1.0f;
+    double total = 0.0;
+    for (size_t R = 0; R < rows; R++) total += row_sum[R];
+    if (!(total > 0.0)) { marg[rows] = 0.0f; return; }  // a black map is no light
+    double run = 0.0;
+    for (size_t R = 0; R + 1 < rows; R++) {
+        run += row_sum[R];
+        marg[R] = (float)(run / total);
+    }
 }
 
 // ------------------------------------------------------------------------------------------ camera
@@ -146,7 +204,9 @@ bool HostScene::pack(int n_threads, std::string &err) {
     L.planes = section(planes.size() * 32);
     L.lights = section(lights.size() * 32);
     L.materials = section(materials.size() * 32);
-    const size_t env_bytes = env.present() ? (env.rgbe.empty() ? env.f32.size() * 4 : env.rgbe.size() * 4) : 0;
+    const size_t env_face_bytes = env.present() ? (env.rgbe.empty() ? env.f32.size() * 4 : env.rgbe.size() * 4) : 0;
+    const EnvSection env_sec = env_section(env.w, env.h, !env.rgbe.empty());
+    const size_t env_bytes = env.present() ? env_sec.bytes : 0;
     L.env = section(env_bytes);
     L.total = off;
     // The big sections [0, L.meshes).  With a device and a large mesh they are made ON that device (pack_gpu.hip: the same
@@ -452,7 +512,10 @@ bool HostScene::pack(int n_threads, std::string &err) {
         const float v[8] = {m.kd[0], m.kd[1], m.kd[2], 0, m.ks[0], m.ks[1], m.ks[2], 0};
         memcpy(ma + 8 * i, v, 32);
     }
-    if (env_bytes) memcpy(T + L.env, env.rgbe.empty() ? (const void *)env.f32.data() : (const void *)env.rgbe.data(), env_bytes);
+    if (env_bytes) {
+        memcpy(T + L.env, env.rgbe.empty() ? (const void *)env.f32.data() : (const void *)env.rgbe.data(), env_face_bytes);
+        build_env_light(env, reinterpret_cast<float *>(T + L.env + env_sec.marg), reinterpret_cast<float *>(T + L.env + env_sec.cond), n_threads);
+    }
     (void)f2u;
     if (packed_on_gpu) {
         std::string gpu_err;
@@ -556,7 +619,8 @@ bool import_blob(HostScene &s, const uint8_t *blob, size_t size, std::string &er
         fits(L.meshes, (uint64_t)h.n_meshes, sizeof(DMesh)) && fits(L.mesh_order, (uint64_t)3 * (uint64_t)h.n_meshes, 4) &&
         fits(L.spheres, (uint64_t)h.n_spheres, 32) && fits(L.planes, (uint64_t)h.n_planes, 32) &&
         fits(L.lights, (uint64_t)h.n_lights, 32) && fits(L.materials, (uint64_t)h.n_materials, 32) &&
-        fits(L.env, env_texels, h.env_is_rgbe ? 4 : 12);
+        fits(L.env, env_texels, h.env_is_rgbe ? 4 : 12) &&
+        (env_texels == 0 || fits(L.env, (uint64_t)env_section(h.env_w, h.env_h, h.env_is_rgbe != 0).bytes, 1));
     if (!sections_ok) { err = "scene blob: a section does not fit in the arena"; return false; }
     if (h.total_nodes >= (int64_t)kIdxMask || h.total_refs >= (int64_t)INT32_MAX || h.total_tris >= (int64_t)(INT32_MAX / 4)) {
         err = "scene blob: counts beyond the index widths of the layout";
@@ -652,6 +716,9 @@ DScene HostScene::view(const void *base_v) const {
     if (env.present()) {
         if (env.rgbe.empty()) d.env_f32 = reinterpret_cast<const float *>(base + layout.env);
         else d.env_rgbe = reinterpret_cast<const uint32_t *>(base + layout.env);
+        const EnvSection es = env_section(env.w, env.h, !env.rgbe.empty());
+        d.env_marg = reinterpret_cast<const float *>(base + layout.env + es.marg);
+        d.env_cond = reinterpret_cast<const float *>(base + layout.env + es.cond);
     }
     d.n_meshes = (int32_t)meshes.size();
     d.n_spheres = (int32_t)spheres.size();

@@ -27,6 +27,21 @@ struct HostEnv {
     std::vector<float> f32;      // 6*w*h*3 when given as floats
     bool present() const { return w > 0; }
 };
+// The env section of the arena: the six faces, then the sampling tables of the map as a light (use_envmap == 2; scene.cpp
+// build_env_light): marg[6 h + 1] (CDF over all rows; the extra entry is 1.0f when the map can be sampled, 0.0f when it is
+// black), cond[6 h][w] (CDF inside a row).  Offsets relative to the section, each 256-byte aligned.
+struct EnvSection {
+    size_t marg = 0, cond = 0, bytes = 0;
+};
+inline EnvSection env_section(int w, int h, bool is_rgbe) {
+    EnvSection e;
+    if (w <= 0 || h <= 0) return e;
+    const size_t faces = (size_t)6 * w * h * (is_rgbe ? 4 : 12);
+    e.marg = (faces + 255) & ~(size_t)255;
+    e.cond = (e.marg + ((size_t)6 * h + 1) * 4 + 255) & ~(size_t)255;
+    e.bytes = e.cond + (size_t)6 * h * w * 4;
+    return e;
+}
 
 // Byte offsets of each section inside the arena (all 256-byte aligned).
 struct ArenaLayout {

@@ -114,6 +114,8 @@ struct DScene {
     const f4 *materials;  // 2 per material: (diffuse, -) (mirror, -)
     const uint32_t *env_rgbe;  // 6*w*h texels R|G<<8|B<<16|E<<24, or null
     const float *env_f32;      // 6*w*h*3 floats, or null
+    const float *env_marg;     // the map as a light (use_envmap == 2): CDF over the 6*h rows, + 1 entry: 1.0f = usable
+    const float *env_cond;     // CDF inside each row, [6*h][w]
     int32_t n_meshes, n_spheres, n_planes, n_lights, n_materials, total_tris;
     int32_t env_w, env_h;
     float cam_eye[3], cam_lookat[3], cam_right[3], cam_up[3];

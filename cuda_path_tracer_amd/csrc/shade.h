@@ -155,6 +155,65 @@ PT_HD float sample_mirror(f3 N, f3 in, f3 &out) {
     return 1.0f;
 }
 
+// One texel of the cube map, decoded as HDRLoader's convertComponent does (HDRLoader.cu:99-104)
+PT_HD f3 env_texel(const DScene &sc, size_t texel) {
+    if (sc.env_rgbe) {
+        const uint32_t px = sc.env_rgbe[texel];
+        const int expo = (int)(px >> 24) - 128;
+        const float scale = ldexpf(1.0f, expo);  // (float)pow(2, expo), exact
+        return mk3(((int)(px & 255u) / 256.0f) * scale, ((int)((px >> 8) & 255u) / 256.0f) * scale,
+                   ((int)((px >> 16) & 255u) / 256.0f) * scale);
+    }
+    const float *c = sc.env_f32 + texel * 3;
+    return mk3(c[0], c[1], c[2]);
+}
+
+// ---- The cube map as a LIGHT (mipt_render_config.use_envmap == 2).  No counterpart in the reference, which only looks
+// radiance up; a build-defined extension like the miss term.  A texel stands for the direction through its
+// centre and is drawn with probability proportional to average(rgb) x solid angle from two CDF tables in the arena (packed
+// by scene.cpp build_env_light: env_marg over all 6 h rows, env_cond inside a row).
+// Direction (not normalised) and solid angle of texel (face, row, col): the inverse of env_lookup's index formulas, face by
+// face -- env_lookup(dir) lands in this texel again (tests/test_env_light.py).
+PT_HD void env_texel_geometry(int face, int row, int col, int w, int h, f3 &dir, float &solid_angle) {
+    const float fu = ((float)col + 0.5f) / (float)w, fv = ((float)row + 0.5f) / (float)h;
+    const float a = 2.0f * fu - 1.0f, b = 2.0f * fv - 1.0f;
+    const float len2 = 1.0f + a * a + b * b;
+    solid_angle = (4.0f / ((float)w * (float)h)) / (len2 * sqrtf(len2));
+    switch (face) {
+        case 0: dir = mk3(1.0f, -b, -a); break;
+        case 3: dir = mk3(-1.0f, -b, a); break;
+        case 1: dir = mk3(a, 1.0f, b); break;
+        case 4: dir = mk3(a, -1.0f, -b); break;
+        case 2: dir = mk3(a, -b, 1.0f); break;
+        default: dir = mk3(-a, -b, -1.0f); break;
+    }
+}
+// first index whose CDF entry is >= u (u in (0, 1]; the last entry is 1)
+PT_HD int cdf_search(const float *cdf, int n, float u) {
+    int lo = 0, hi = n - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (cdf[mid] < u) lo = mid + 1;
+        else hi = mid;
+    }
+    return lo;
+}
+PT_HD bool env_light_usable(const DScene &sc) { return sc.env_marg != nullptr && sc.env_marg[6 * sc.env_h] != 0.0f; }
+// One importance sample: direction (not normalised), solid angle, probability and radiance of the texel (u1, u2) select.
+PT_HD bool env_light_sample(const DScene &sc, float u1, float u2, f3 &dir, float &solid_angle, float &pmf, f3 &radiance) {
+    const int w = sc.env_w, h = sc.env_h;
+    const int R = cdf_search(sc.env_marg, 6 * h, u1);
+    const float *cond = sc.env_cond + (size_t)R * w;
+    const int c = cdf_search(cond, w, u2);
+    const float p_row = sc.env_marg[R] - (R > 0 ? sc.env_marg[R - 1] : 0.0f);
+    const float p_col = cond[c] - (c > 0 ? cond[c - 1] : 0.0f);
+    pmf = p_row * p_col;
+    const int face = R / h, row = R - face * h;
+    env_texel_geometry(face, row, c, w, h, dir, solid_angle);
+    radiance = env_texel(sc, (size_t)face * w * h + (size_t)row * w + c);
+    return pmf > 0.0f;
+}
+
 // EnvMap::getPixelColor: nearest texel, flattened index clamped only above (Q19); faces px,py,pz,nx,ny,nz
 PT_HD f3 env_lookup(const DScene &sc, f3 d) {
     const int W = sc.env_w, H = sc.env_h;
@@ -171,16 +230,7 @@ PT_HD f3 env_lookup(const DScene &sc, f3 d) {
     }
     if (pos > H * W * 3 - 3) pos = H * W * 3 - 3;
     if (pos < 0) pos = 0;
-    const size_t texel = (size_t)face * W * H + (size_t)(pos / 3);
-    if (sc.env_rgbe) {
-        const uint32_t px = sc.env_rgbe[texel];
-        const int expo = (int)(px >> 24) - 128;
-        const float scale = ldexpf(1.0f, expo);  // (float)pow(2, expo), exact
-        return mk3(((int)(px & 255u) / 256.0f) * scale, ((int)((px >> 8) & 255u) / 256.0f) * scale,
-                   ((int)((px >> 16) & 255u) / 256.0f) * scale);
-    }
-    const float *c = sc.env_f32 + texel * 3;
-    return mk3(c[0], c[1], c[2]);
+    return env_texel(sc, (size_t)face * W * H + (size_t)(pos / 3));
 }
 
 }  // namespace mipt

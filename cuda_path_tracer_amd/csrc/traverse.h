@@ -643,6 +643,7 @@ PT_HD bool misses_every_mesh(const DScene &sc, f3 o, f3 d) {
 // it was aimed at?  target.w == 0: ray cast from the light at a surface point (kernel.cu:249); else: connection ray
 // from a camera vertex to a light vertex (kernel.cu:268).  One definition for every stage that resolves a shadow ray.
 PT_HD bool shadow_visible(f3 o, f3 d, float t, f4 target) {
+    if (target.w == 2.0f) return t < 0.0f;  // a ray towards the cube map as a light (use_envmap == 2): it must leave the scene
     const f3 P = ray_at(o, d, t);
     const float dist = len3(P - mk3(target.x, target.y, target.z));
     if (target.w == 0.0f) return (t > 0.0f) && (dist < kEps);

@@ -213,8 +213,10 @@ struct PassParams {
     int sample0;         // sample index of slot 0 of this pass
     int sample_stride;   // sample index step between slots
     int n_slots;         // valid slots in this pass (paths = n_slots * npix)
-    int Dc, Dl, K;       // camera depth, light depth, shadow slots per path (1 + Dl)
+    int Dc, Dl, K;       // camera depth, light depth, shadow slots per path (1 + Dl, + 1 with env_light)
     int use_env;
+    int env_light;       // use_envmap == 2: the cube map is also sampled as a light at every camera vertex (shade.h); its
+                         // shadow ray sits in slot 1 + Dl of the path
     uint32_t seed;
     int tiles_x;         // > 0: paths of a sample are laid out in 8x8 pixel tiles (W and H multiples of 8), else row-major
     int common_origins;  // simple integrator, persistent extend kernel: primary rays and direct-connection rays are launched
@@ -423,7 +425,10 @@ __global__ __launch_bounds__(kBlock) void k_light_shade(DScene sc, PassParams pp
 }
 
 // camera sub-path vertex i (kernel.cu:239-303)
-__global__ __launch_bounds__(kBlock) void k_shade(DScene sc, PassParams pp, WfBuffers b, int i) {
+// ENVL: the instantiation that also samples the cube map as a light (use_envmap == 2).  A template parameter, not a run-time
+// flag: as a flag the extra live state cost the default kernel 57 % (5.3 -> 8.3 ms per launch on the 1080p frame).
+template <bool ENVL>
+__global__ __launch_bounds__(kBlock, 4) void k_shade(DScene sc, PassParams pp, WfBuffers b, int i) {
     __shared__ int ap_lds[2 * (kWaves + 1)];
     __shared__ int ap3_lds[2 * 3 * kWaves];
     int phase = 0, phase3 = 0;
@@ -431,6 +436,9 @@ __global__ __launch_bounds__(kBlock) void k_shade(DScene sc, PassParams pp, WfBu
     const int n = b.counts[kCntPad * (kCntCam + i)];
     const int par = i & 1;
     const bool by_id = (i == 0) && (pp.Dl != 0);  // bidirectional vertex 0: the alive set is a list of path ids
+    // the cube map as a light (build-defined, oracle.cpp trace_sample): two draws and one shadow ray per vertex; a ray that
+    // leaves the scene then collects the map only at vertex 0 and behind a mirror bounce (bit 31 of the path's draw word)
+    const bool env_light = ENVL && env_light_usable(sc);
     for (int base = blockIdx.x * kBlock; base < n; base += gridDim.x * kBlock) {
         const int idx = base + threadIdx.x;
         bool cont = false;
@@ -453,7 +461,7 @@ __global__ __launch_bounds__(kBlock) void k_shade(DScene sc, PassParams pp, WfBu
             Tc = xyz(Tp);
             pc = Tp.w;
             if (h.prim < 0) {
-                if (pp.use_env) {  // build-defined extension: radiance of the cube map on a miss
+                if (pp.use_env && (!env_light || i == 0 || (as_u32(o4.w) >> 31) != 0u)) {  // build-defined extension: radiance of the cube map on a miss
                     f4 r = b.path_rad[pid];
                     const f3 add = (Tc / pc) * env_lookup(sc, d);
                     r.x = r.x + add.x; r.y = r.y + add.y; r.z = r.z + add.z;
@@ -500,11 +508,31 @@ __global__ __launch_bounds__(kBlock) void k_shade(DScene sc, PassParams pp, WfBu
                     b.sh_contrib[si] = mk4(contrib, as_f32((uint32_t)pid));
                     mask |= 1u << (1 + jj);
                 }
-                if (i + 1 < pp.Dc) {  // next vertex (Q16); nothing downstream reads it after the last vertex
+                if (i + 1 < pp.Dc || env_light) {  // next vertex (Q16); nothing downstream reads it after the last vertex
                     const int slot = pid / pp.npix, pixel = pixel_of(pp, pid - slot * pp.npix);
                     Rng rng;
                     rng.init(pp.seed, (uint32_t)pixel, (uint32_t)(pp.sample0 + slot * pp.sample_stride),
-                             by_id ? b.path_rng[pid] : as_u32(o4.w));
+                             (by_id ? b.path_rng[pid] : as_u32(o4.w)) & 0x7fffffffu);
+                    if (env_light) {  // two draws, always; the contribution waits for its shadow ray in slot 1 + Dl
+                        const float u1 = rng.u(), u2 = rng.u();
+                        f3 edir, erad;
+                        float sa, pmf;
+                        if (env_light_sample(sc, u1, u2, edir, sa, pmf, erad)) {
+                            const f3 wdir = norm3(edir);
+                            const float ct = dot3(s.nrm, wdir);
+                            if (ct > kEps) {
+                                const f3 brdf = s.kd / kPi;
+                                const f3 contrib = ((Tc / pc) * (erad * brdf * ct)) * (sa / pmf);
+                                const size_t si = sbase + 1 + pp.Dl;
+                                b.sh_o[si] = mk4(s.pos + s.nrm * kEps, 0.f);
+                                b.sh_d[si] = mk4(norm3(wdir), 0.f);
+                                b.sh_target[si] = mk4(mk3(0.f, 0.f, 0.f), 2.f);
+                                b.sh_contrib[si] = mk4(contrib, as_f32((uint32_t)pid));
+                                mask |= 1u << (1 + pp.Dl);
+                            }
+                        }
+                    }
+                  if (i + 1 < pp.Dc) {
                     const float pd = avg3(s.kd), pm = avg3(s.ks);
                     const float rnd = rng.u();
                     f3 od;
@@ -521,12 +549,14 @@ __global__ __launch_bounds__(kBlock) void k_shade(DScene sc, PassParams pp, WfBu
                         Tc = Tc * s.ks;
                         pc = pc * pdf * pm;
                         cont = true;
+                        if (env_light) rng.draw |= 0x80000000u;  // behind a mirror bounce a miss still collects the map
                     }
                     draw = rng.draw;
                     if (cont) {
                         nro = s.pos + s.nrm * kEps;
                         nrd = norm3(od);
                     }
+                  }
                 }
             }
         }
@@ -756,7 +786,7 @@ int wavefront_render(const HostScene &hs, DeviceCtx &dc, const mipt_render_confi
     int64_t n_samples = 0;
     if (cfg.sample_end > cfg.sample_begin) n_samples = ((int64_t)cfg.sample_end - cfg.sample_begin + stride - 1) / stride;
     const int npix = cfg.width * cfg.height;
-    const int Dc = cfg.cam_depth, Dl = cfg.light_depth, K = 1 + Dl;
+    const int Dc = cfg.cam_depth, Dl = cfg.light_depth, K = 1 + Dl + (cfg.use_envmap == 2 ? 1 : 0);
     WF_TRY(hipSetDevice(dc.device));
     if (n_samples == 0 || Dc == 0) return 0;
     int S = cfg.samples_per_pass;
@@ -846,7 +876,7 @@ int wavefront_render(const HostScene &hs, DeviceCtx &dc, const mipt_render_confi
     const int path_grid = (int)std::min<size_t>((P + kBlock - 1) / kBlock, (size_t)dc.num_cus * 16);
 
     pp.W = cfg.width; pp.H = cfg.height; pp.npix = npix; pp.spp = cfg.spp; pp.sample_stride = stride;
-    pp.Dc = Dc; pp.Dl = Dl; pp.K = K; pp.use_env = cfg.use_envmap ? 1 : 0; pp.seed = cfg.seed;
+    pp.Dc = Dc; pp.Dl = Dl; pp.K = K; pp.use_env = cfg.use_envmap ? 1 : 0; pp.env_light = cfg.use_envmap == 2 ? 1 : 0; pp.seed = cfg.seed;
     pp.tiles_x = (cfg.width % 8 == 0 && cfg.height % 8 == 0) ? cfg.width / 8 : 0;
     pp.common_origins = (K == 1 && !dc.extend_simple) ? 1 : 0;
 
@@ -877,7 +907,8 @@ int wavefront_render(const HostScene &hs, DeviceCtx &dc, const mipt_render_confi
             {
                 hipEvent_t a = dc.events.next(), e = dc.events.next();
                 (void)hipEventRecord(a, sm);
-                hipLaunchKernelGGL(k_shade, dim3(path_grid), dim3(kBlock), 0, sm, dc.view, pp, b, i);
+                if (pp.env_light) hipLaunchKernelGGL(k_shade<true>, dim3(path_grid), dim3(kBlock), 0, sm, dc.view, pp, b, i);
+                else hipLaunchKernelGGL(k_shade<false>, dim3(path_grid), dim3(kBlock), 0, sm, dc.view, pp, b, i);
                 (void)hipEventRecord(e, sm);
                 shade_ev.emplace_back(a, e);
             }

@@ -29,7 +29,7 @@ def _ptr(a):
 
 def make_config(width, height, spp, cam_depth=6, light_depth=0, use_envmap=False, seed=0x5EED, sample_begin=0,
                 sample_end=None, sample_stride=1, samples_per_pass=0, flags=0):
-    return RenderConfig(int(width), int(height), int(spp), int(cam_depth), int(light_depth), int(bool(use_envmap)),
+    return RenderConfig(int(width), int(height), int(spp), int(cam_depth), int(light_depth), int(use_envmap),
                         int(seed) & 0xFFFFFFFF, int(sample_begin), int(spp if sample_end is None else sample_end),
                         int(sample_stride), int(samples_per_pass), int(flags))
 

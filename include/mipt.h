@@ -27,7 +27,10 @@ typedef struct mipt_render_config {
     int32_t spp;             /* nSamples (constants.cuh:9): normalisation constant, kernel.cu:343 */
     int32_t cam_depth;       /* camera sub-path vertices (maxdepth, constants.cuh:8)              */
     int32_t light_depth;     /* light sub-path vertices; 0 = "simple" path tracing (README.md:17) */
-    int32_t use_envmap;      /* add cube-map radiance on a camera-ray miss (img/environment_mapping.png) */
+    int32_t use_envmap;      /* 1: add cube-map radiance on a camera-ray miss (img/environment_mapping.png); 2 (build-defined,
+                                no counterpart in the reference): ... and sample the map as a LIGHT at every camera vertex
+                                (texels drawn in proportion to radiance x solid angle, one shadow ray each; a ray that leaves
+                                the scene then collects the map only at the first vertex and behind a mirror bounce) */
     uint32_t seed;           /* counter-based RNG key (replaces curand_init, kernel.cu:331)       */
     int32_t sample_begin, sample_end, sample_stride; /* this call renders s = begin, begin+stride, ... < end */
     int32_t samples_per_pass; /* samples of every pixel in flight per wavefront pass; 0 = auto    */

@@ -101,6 +101,8 @@ def load(variant=""):
     lib.orc_philox4x32_10.argtypes = [_VP, _VP, _VP]
     lib.orc_rng_uniform.argtypes = [C.c_uint32] * 4
     lib.orc_env_lookup.argtypes = [_VP, _VP, C.c_int64, _VP, _VP, _VP]
+    lib.orc_env_light_tables.argtypes = [_VP, _VP, _VP]
+    lib.orc_env_light_sample.argtypes = [_VP, C.c_float, C.c_float, _VP, _VP, _VP]
     lib.orc_hdr_load.argtypes = [C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int), _VP]
     lib.orc_srt_matrix.argtypes = [_F3, _F3, _F3, _VP, _VP]
     lib.orc_set_mutations.argtypes = [C.c_uint32]
@@ -231,6 +233,22 @@ class OracleScene:
         pos = np.empty(dirs.shape[0], np.int32)
         _check(self._lib.orc_env_lookup(self._h, _ptr(dirs), dirs.shape[0], _ptr(rgb), _ptr(face), _ptr(pos)))
         return (rgb, face, pos) if with_index else rgb
+
+    def env_light_tables(self, w, h):
+        """(usable, marg[6 h], cond[6 h, w]): the sampling tables of the cube map as a light (use_envmap == 2)."""
+        marg = np.empty(6 * h, np.float32)
+        cond = np.empty((6 * h, w), np.float32)
+        rc = self._lib.orc_env_light_tables(self._h, _ptr(marg), _ptr(cond))
+        _check(min(rc, 0))
+        return bool(rc), marg, cond
+
+    def env_light_sample(self, u1, u2):
+        """The texel two uniform numbers select: (face, row, col), probability, solid angle, direction (not normalised)."""
+        frc = np.empty(3, np.int32)
+        ps = np.empty(2, np.float32)
+        d = np.empty(3, np.float32)
+        _check(self._lib.orc_env_light_sample(self._h, float(u1), float(u2), _ptr(frc), _ptr(ps), _ptr(d)))
+        return tuple(int(x) for x in frc), float(ps[0]), float(ps[1]), d
 
     def mesh_count(self):
         return self._lib.orc_mesh_count(self._h)

@@ -679,6 +679,9 @@ struct orc_scene {
     std::vector<Mesh> meshes;
     HdrImage env[6];  // px,py,pz,nx,ny,nz (envMap.cuh:10-15)
     bool has_env = false;
+    // build-defined extension (use_envmap == 2): the cube map as a light, importance-sampled by texel (see env_light_build)
+    std::vector<float> env_marg, env_cond;
+    bool env_light_ok = false;
     bool committed = false;
     int total_tris = 0;
 };
@@ -856,6 +859,91 @@ inline V3 env_lookup(const orc_scene &sc, V3 d, int *face_out = nullptr, int *po
     return mk(im.cols[pos], im.cols[pos + 1], im.cols[pos + 2]);
 }
 
+// ---- The cube map as a LIGHT (use_envmap == 2).  No counterpart in the reference, which only looks radiance up
+// (envMap.cuh:50-89); a build-defined extension like the miss term itself, restated here operation for operation so that the
+// product's pictures can be held against it bit for bit.  A texel (face f, row r, column c) stands for the direction through
+// its centre; its probability is proportional to average(rgb) x solid angle.  Tables: env_marg[f * H + r] = CDF over all 6 H
+// rows, env_cond[(f * H + r) * W + c] = CDF inside a row; sums in double, in index order, stored as float, last entry 1.
+inline void env_texel_geometry(int face, int row, int col, int w, int h, V3 &dir, float &solid_angle) {
+    const float fu = ((float)col + 0.5f) / (float)w, fv = ((float)row + 0.5f) / (float)h;
+    const float a = 2.0f * fu - 1.0f, b = 2.0f * fv - 1.0f;
+    const float len2 = 1.0f + a * a + b * b;
+    solid_angle = (4.0f / ((float)w * (float)h)) / (len2 * sqrtf(len2));
+    // the inverse of env_lookup's index formulas, face by face: env_lookup(dir) lands in this texel again
+    switch (face) {
+        case 0: dir = mk(1.0f, -b, -a); break;
+        case 3: dir = mk(-1.0f, -b, a); break;
+        case 1: dir = mk(a, 1.0f, b); break;
+        case 4: dir = mk(a, -1.0f, -b); break;
+        case 2: dir = mk(a, -b, 1.0f); break;
+        default: dir = mk(-a, -b, -1.0f); break;
+    }
+}
+void env_light_build(orc_scene &sc) {
+    sc.env_light_ok = false;
+    sc.env_marg.clear();
+    sc.env_cond.clear();
+    if (!sc.has_env) return;
+    const int w = sc.env[0].w, h = sc.env[0].h;
+    const size_t rows = (size_t)6 * h;
+    std::vector<double> row_sum(rows, 0.0);
+    sc.env_cond.assign(rows * w, 1.0f);
+    sc.env_marg.assign(rows, 1.0f);
+    std::vector<double> acc((size_t)w);
+    for (size_t R = 0; R < rows; R++) {
+        const int face = (int)(R / h), row = (int)(R % h);
+        const HdrImage &im = sc.env[face];
+        double run = 0.0;
+        for (int c = 0; c < w; c++) {
+            V3 dir;
+            float sa;
+            env_texel_geometry(face, row, c, w, h, dir, sa);
+            const float *px = &im.cols[((size_t)row * w + c) * 3];
+            const double lum = ((double)px[0] + (double)px[1] + (double)px[2]) / 3.0;
+            const double wgt = (lum > 0.0 && lum < (double)INFINITY) ? lum * (double)sa : 0.0;  // NaN / negative / inf texels get no probability
+            run += wgt;
+            acc[(size_t)c] = run;
+        }
+        row_sum[R] = run;
+        if (run > 0.0)
+            for (int c = 0; c + 1 < w; c++) sc.env_cond[R * w + c] = (float)(acc[(size_t)c] / run);
+    }
+    double total = 0.0;
+    for (size_t R = 0; R < rows; R++) total += row_sum[R];
+    if (!(total > 0.0)) return;  // a black map is no light
+    double run = 0.0;
+    for (size_t R = 0; R + 1 < rows; R++) {
+        run += row_sum[R];
+        sc.env_marg[R] = (float)(run / total);
+    }
+    sc.env_light_ok = true;
+}
+// first index whose CDF entry is >= u (u in (0, 1], the last entry is 1)
+inline int cdf_search(const float *cdf, int n, float u) {
+    int lo = 0, hi = n - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (cdf[mid] < u) lo = mid + 1;
+        else hi = mid;
+    }
+    return lo;
+}
+// One importance sample: the texel, its probability, its direction (not normalised), solid angle and radiance.
+inline bool env_light_sample(const orc_scene &sc, float u1, float u2, V3 &dir, float &solid_angle, float &pmf, V3 &radiance) {
+    const int w = sc.env[0].w, h = sc.env[0].h;
+    const int R = cdf_search(sc.env_marg.data(), 6 * h, u1);
+    const float *cond = &sc.env_cond[(size_t)R * w];
+    const int c = cdf_search(cond, w, u2);
+    const float p_row = sc.env_marg[(size_t)R] - (R > 0 ? sc.env_marg[(size_t)R - 1] : 0.0f);
+    const float p_col = cond[c] - (c > 0 ? cond[c - 1] : 0.0f);
+    pmf = p_row * p_col;
+    const int face = R / h, row = R % h;
+    env_texel_geometry(face, row, c, w, h, dir, solid_angle);
+    const float *px = &sc.env[face].cols[((size_t)row * w + c) * 3];
+    radiance = mk(px[0], px[1], px[2]);
+    return pmf > 0.0f;
+}
+
 struct LightVertex {
     Hit hit;
     V3 T;
@@ -910,10 +998,15 @@ V3 trace_sample(const orc_scene &sc, const orc_render_config &cfg, Ray cam_ray, 
     }
     V3 Tc = mk(1, 1, 1);
     float pc = 1.0f;
+    // use_envmap == 2 (build-defined): the map is ALSO sampled as a light at every camera vertex; a ray that leaves the scene
+    // then only collects the map where the sampling cannot have: at the first vertex and behind a mirror bounce
+    const bool env_light = cfg.use_envmap == 2 && sc.has_env && sc.env_light_ok;
+    bool after_mirror = false;
     for (int i = 0; i < Dc; i++) {  // :239-303
         Hit hit = first_intersect(sc, cam_ray, c);
         if (hit.t < 0) {
-            if (cfg.use_envmap && sc.has_env) out = out + (Tc / pc) * env_lookup(sc, cam_ray.d);  // build-defined
+            if (cfg.use_envmap && sc.has_env && (!env_light || i == 0 || after_mirror))
+                out = out + (Tc / pc) * env_lookup(sc, cam_ray.d);  // build-defined
             break;
         }
         const Material &m = sc.mats[hit.mat];
@@ -963,6 +1056,22 @@ V3 trace_sample(const orc_scene &sc, const orc_render_config &cfg, Ray cam_ray, 
             }
             out = out + lw * G * cw;
         }
+        if (env_light) {  // two draws, always; the shadow ray must leave the scene
+            const float u1 = rng.u(), u2 = rng.u();
+            V3 edir, erad;
+            float sa, pmf;
+            if (env_light_sample(sc, u1, u2, edir, sa, pmf, erad)) {
+                const V3 wdir = normalize(edir);
+                const float ct = dot(hit.nrm, wdir);
+                if (ct > EPS) {
+                    Hit sh = first_intersect(sc, make_ray(hit.pos + hit.nrm * EPS, wdir), c);
+                    if (sh.t < 0) {
+                        V3 brdf = m.kd / PI;
+                        out = out + ((Tc / pc) * (erad * brdf * ct)) * (sa / pmf);
+                    }
+                }
+            }
+        }
         float pd = average(m.kd), pm = average(m.ks);  // :283-300 (Q16)
         float rnd = rng.u();
         V3 od;
@@ -972,10 +1081,12 @@ V3 trace_sample(const orc_scene &sc, const orc_render_config &cfg, Ray cam_ray, 
             if (ct < EPS) break;
             Tc = Tc * m.kd / PI * ct;
             pc = MUT(MUT_Q16_ROULETTE_PDF) ? pc * pdf : pc * pdf * pd;
+            after_mirror = false;
         } else if (rnd < pd + pm) {
             float pdf = sample_mirror(hit.nrm, cam_ray.d, od);
             Tc = Tc * m.ks;
             pc = MUT(MUT_Q16_ROULETTE_PDF) ? pc * pdf : pc * pdf * pm;
+            after_mirror = true;
         } else {
             break;
         }
@@ -1138,6 +1249,7 @@ int orc_scene_commit(orc_scene *s, int n_threads) {
         if (m.nodes.empty()) build_mesh_tree(m);
     }
     s->total_tris = base;
+    env_light_build(*s);
     s->committed = true;
     return 0;
 }
@@ -1299,6 +1411,29 @@ float orc_rng_uniform(uint32_t seed, uint32_t pixel, uint32_t sample, uint32_t d
     Rng r(seed, pixel, sample);
     r.draw = draw;
     return r.u();
+}
+// The sampling tables of the cube map as a light (after commit): marg[6 H], cond[6 H W]; returns 1 if the map can be sampled
+// (it exists and is not black), 0 if not, < 0 on error.  Null pointers: only the answer.
+int orc_env_light_tables(orc_scene *s, float *marg, float *cond) {
+    if (!s->committed) return fail("oracle: scene not committed");
+    if (!s->has_env) return 0;
+    if (marg) memcpy(marg, s->env_marg.data(), s->env_marg.size() * sizeof(float));
+    if (cond) memcpy(cond, s->env_cond.data(), s->env_cond.size() * sizeof(float));
+    return s->env_light_ok ? 1 : 0;
+}
+// The texel a pair of uniform numbers selects: face, row, column, probability, solid angle, direction (not normalised).
+int orc_env_light_sample(orc_scene *s, float u1, float u2, int32_t *frc, float *pmf_sa, float *dir) {
+    if (!s->committed || !s->env_light_ok) return fail("oracle: no sampled env map");
+    V3 d, rad;
+    float sa, pmf;
+    env_light_sample(*s, u1, u2, d, sa, pmf, rad);
+    const int w = s->env[0].w, h = s->env[0].h;
+    const int R = cdf_search(s->env_marg.data(), 6 * h, u1);
+    const int c = cdf_search(&s->env_cond[(size_t)R * w], w, u2);
+    frc[0] = R / h; frc[1] = R % h; frc[2] = c;
+    pmf_sa[0] = pmf; pmf_sa[1] = sa;
+    dir[0] = d.x; dir[1] = d.y; dir[2] = d.z;
+    return 0;
 }
 int orc_env_lookup(orc_scene *s, const float *dirs, int64_t n, float *rgb, int32_t *face, int32_t *pos) {
     if (!s->has_env) return fail("oracle: no env map");

@@ -36,7 +36,8 @@ typedef struct orc_render_config {
     int32_t spp;            /* total samples per pixel (normalisation constant, kernel.cu:343) */
     int32_t cam_depth;      /* camera sub-path vertices (maxdepth, constants.cuh:8) */
     int32_t light_depth;    /* light sub-path vertices; 0 = "simple" path tracing */
-    int32_t use_envmap;     /* add env radiance on camera-ray miss (build-defined) */
+    int32_t use_envmap;     /* 1: add env radiance on camera-ray miss (build-defined); 2: ... and sample the map as
+                               a light at every camera vertex (the miss term then only at vertex 0 and behind mirror bounces) */
     uint32_t seed;
     int32_t sample_begin, sample_end, sample_stride; /* samples s = begin, begin+stride, ... < end */
     int32_t pixel_stride;   /* oracle only: render every k-th pixel (others left 0); 1 = all */
@@ -113,6 +114,9 @@ void orc_sincos(float x, float *s, float *c);
 void orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
 float orc_rng_uniform(uint32_t seed, uint32_t pixel, uint32_t sample, uint32_t draw);
 int orc_env_lookup(orc_scene *, const float *dirs, int64_t n, float *rgb, int32_t *face, int32_t *pos);
+/* the cube map as a light (use_envmap == 2, build-defined): sampling tables marg[6 H], cond[6 H W] (may be NULL); 1 = usable */
+int orc_env_light_tables(orc_scene *, float *marg, float *cond);
+int orc_env_light_sample(orc_scene *, float u1, float u2, int32_t frc[3], float pmf_sa[2], float dir[3]);
 int orc_hdr_load(const char *path, int *w, int *h, float *cols /* may be NULL */);
 void orc_srt_matrix(const float scale[3], const float rotate[3], const float translate[3], float m16[16],
                     float inv_t16[16]);

@@ -88,6 +88,13 @@ def test_c4_full_frame_simple_and_bidirectional_and_its_nonfinite_samples():
         if kw["light_depth"]:
             # Q11 (kernel.cu:185): in an open scene a first light ray that escapes zeroes the whole sample
             assert (a == 0).all(axis=1).mean() > 0.2
+        # the same frame with the cube map also sampled as a light (use_envmap == 2, build-defined): 8.3 M more shadow rays
+        cfg.use_envmap = 2
+        img2, _ = s.render(cfg)
+        ref2, _ = o.render(cfg, pixel_stride=STRIDE)
+        a2, b2 = img2.reshape(-1, 3)[sel], ref2.reshape(-1, 3)[sel]
+        assert np.array_equal(a2.view(np.uint32), b2.view(np.uint32)), ("env light", kw)
+        assert not np.array_equal(a2, a)
     for smp, pix in C4_NONFINITE:
         cfg = make_config(W, H, spp=1024, cam_depth=6, light_depth=0, use_envmap=True, sample_begin=smp, sample_end=smp + 1)
         img, st = s.render(cfg)

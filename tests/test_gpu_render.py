@@ -90,6 +90,33 @@ def test_mirror_sphere_and_envmap():
     assert np.array_equal(img.view(np.uint32), ref.view(np.uint32)), np.abs(img - ref).max()
 
 
+@pytest.mark.parametrize("rgbe", [False, True])
+def test_env_map_as_a_light_bit_exact(rgbe, tmp_path):
+    """use_envmap == 2 (build-defined, no counterpart in the reference): texels drawn in proportion to radiance x solid angle,
+    one more shadow ray per camera vertex, the miss term only at vertex 0 and behind mirror bounces.  Simple and bidirectional,
+    one and several passes, a one-vertex path (the sample is taken at the LAST vertex too), a mirror ball, a mesh."""
+    from tests.hdr_util import random_rgbe, write_hdr
+    if rgbe:
+        for i, f in enumerate(("px", "py", "pz", "nx", "ny", "nz")):
+            write_hdr(str(tmp_path / (f + ".hdr")), random_rgbe(16, 16, seed=40 + i), rle=(i % 2 == 0))
+        desc = G.scene_env_sphere(level=3, env_dir=str(tmp_path) + "/")
+    else:
+        faces = G.synthetic_env_faces(16)
+        faces[1, 3:5, 8:10] = 900.0   # a sun
+        desc = G.scene_env_sphere(level=3, env_f32=faces)
+    desc.spheres.append(((3.0, -3.0, 0.0), 1.5, 1))
+    s, o = _pair(desc)
+    for dc, dl, spp_pass in ((4, 0, 0), (1, 0, 0), (5, 0, 2), (3, 2, 0), (2, 4, 1)):
+        cfg = make_config(64, 48, spp=3, cam_depth=dc, light_depth=dl, use_envmap=2, samples_per_pass=spp_pass)
+        img, st = s.render(cfg)
+        ref, _ = o.render(cfg)
+        assert np.array_equal(img.view(np.uint32), ref.view(np.uint32)), (dc, dl, spp_pass, np.abs(img - ref).max())
+        cfg.use_envmap = 1
+        assert not np.array_equal(ref, o.render(cfg)[0])       # the mode does change the picture ...
+    cfg = make_config(64, 48, spp=3, cam_depth=4, light_depth=0, use_envmap=1)
+    assert np.array_equal(s.render(cfg)[0].view(np.uint32), o.render(cfg)[0].view(np.uint32))   # ... and mode 1 is what it was
+
+
 def test_env_lookup_matches_oracle():
     desc = G.scene_env_sphere(level=1, env_f32=G.synthetic_env_faces(8))
     s, o = _pair(desc)
