@@ -16,7 +16,7 @@ timeout -k 10 600 python bench.py --save-pmc $O/pmc_bench.json > $O/bench_defaul
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -- python bench.py --no-pmc --no-cpu-baseline --no-closest --no-other-configs > $O/bench_under_rocprof.json 2> $O/bench_under_rocprof.err
 cp $(find $O/prof -name "*kernel_stats.csv" | head -1) $O/kernel_stats.csv
 rm -rf $O/prof
-timeout -k 10 900 python scripts/bench_configs.py C1 C3 C4 C5 > $O/other_configs.log 2>&1
+timeout -k 10 900 python scripts/bench_configs.py C1 C3 C4 C4L C5 > $O/other_configs.log 2>&1
 grep '^{' $O/other_configs.log > $O/other_configs.jsonl
 if [ -f variants/libmipt_stats.so ]; then
   MIPT_LIB=variants/libmipt_stats.so timeout -k 10 300 python scripts/phase_lane_use.py > $O/phase_lane_use.txt 2>&1
