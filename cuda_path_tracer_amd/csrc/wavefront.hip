@@ -781,6 +781,7 @@ int wavefront_render(const HostScene &hs, DeviceCtx &dc, const mipt_render_confi
         err = "path depth out of range (0..16)";
         return -1;
     }
+    if (cfg.use_envmap < 0 || cfg.use_envmap > 2) { err = "use_envmap must be 0 (off), 1 (radiance on a miss) or 2 (... and the map sampled as a light)"; return -1; }
     if (cfg.use_envmap && !hs.env.present()) { err = "use_envmap set but the scene has no environment map"; return -1; }
     const int stride = cfg.sample_stride > 0 ? cfg.sample_stride : 1;
     int64_t n_samples = 0;

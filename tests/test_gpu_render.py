@@ -185,6 +185,8 @@ def test_render_argument_errors():
         s.render(make_config(0, 16, spp=1))
     with pytest.raises(MiptError, match="environment map"):
         s.render(make_config(16, 16, spp=1, use_envmap=True))
+    with pytest.raises(MiptError, match="use_envmap must be"):
+        s.render(make_config(16, 16, spp=1, use_envmap=3))
     nolight = G.scene_icosphere_room(2)
     nolight.lights.clear()
     s2 = nolight.apply(Scene())
